@@ -1,0 +1,118 @@
+"""Deterministic synthetic scenes of SURVEY.md 8(d), written independently of the product's
+scene generator (ray-marching_amd/csrc/host/scenes.hpp) so that the two can be compared
+word for word.  A scene is (nodes, root) with nodes = [(kind, params, lhs, rhs), ...] in the
+flat-table form oracle.cbind.serialize() takes."""
+SPHERE, BOX, UNION, SUBTRACTION = 0, 1, 100, 101
+
+
+def _f32(x):
+    import struct
+    return struct.unpack("<f", struct.pack("<f", x))[0]
+
+
+class _Tab:
+    def __init__(self):
+        self.nodes = []
+
+    def sphere(self, c, r):
+        self.nodes.append((SPHERE, [c[0], c[1], c[2], r], -1, -1))
+        return len(self.nodes) - 1
+
+    def box(self, c, r):
+        self.nodes.append((BOX, [c[0], c[1], c[2], r[0], r[1], r[2]], -1, -1))
+        return len(self.nodes) - 1
+
+    def op(self, kind, a, b):
+        self.nodes.append((kind, [], a, b))
+        return len(self.nodes) - 1
+
+
+def g1():
+    t = _Tab()
+    return t.nodes, t.sphere((0, 0, 0), 1.0)
+
+
+def g8():
+    t = _Tab()
+    s0 = t.sphere((0, 0, 0), 1.0)
+    b1 = t.box((0, 0, 0), (0.8, 0.8, 0.8))
+    s2 = t.sphere((0.9, 0.5, 0.6), 0.6)
+    b3 = t.box((0, -1.2, 0), (1.5, 0.1, 1.5))
+    root = t.op(UNION, t.op(SUBTRACTION, t.op(UNION, s0, b1), s2), b3)
+    return t.nodes, root
+
+
+class _LCG:
+    def __init__(self, seed):
+        self.x = seed & 0xFFFFFFFF
+
+    def u(self):
+        self.x = (1664525 * self.x + 1013904223) & 0xFFFFFFFF
+        return (self.x >> 8) / 16777216.0
+
+
+def _grid_prims(t, nx, nz, seed):
+    rng = _LCG(seed)
+    prims = []
+    for k in range(nx * nz):
+        ix, iz = k % nx, k // nx
+        x = (ix - (nx - 1) / 2.0) * 1.1
+        z = (iz - (nz - 1) / 2.0) * 1.1
+        u1 = rng.u()
+        u2 = rng.u()
+        y = 0.3 * u1
+        if (ix + iz) % 2 == 0:
+            prims.append(t.sphere((x, y, z), 0.35 + 0.15 * u2))
+        else:
+            h = 0.3 + 0.15 * u2
+            prims.append(t.box((x, y, z), (h, h, h)))
+    return prims
+
+
+def _fold_left(t, prims):
+    acc = prims[0]
+    for k in range(len(prims) - 1):
+        acc = t.op(SUBTRACTION if k % 4 == 3 else UNION, acc, prims[k + 1])
+    return acc
+
+
+def g32():
+    t = _Tab()
+    return t.nodes, _fold_left(t, _grid_prims(t, 4, 4, 0x5DF00020))
+
+
+def g64():
+    t = _Tab()
+    return t.nodes, _fold_left(t, _grid_prims(t, 8, 4, 0x5DF00040))
+
+
+def g32_balanced():
+    """Same primitives as g32, combined by a balanced binary tree (stack depth 5)."""
+    t = _Tab()
+    level = _grid_prims(t, 4, 4, 0x5DF00020)
+    k = 0
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), 2):
+            nxt.append(t.op(SUBTRACTION if k % 4 == 3 else UNION, level[i], level[i + 1]))
+            k += 1
+        level = nxt
+    return t.nodes, level[0]
+
+
+def right_deep(n):
+    """Union(S0, Union(S1, Union(S2, ...))) -- needs a value stack n deep."""
+    t = _Tab()
+    prims = [t.sphere((0.7 * (i - (n - 1) / 2.0), 0.1 * (i % 3), 0.0), 0.3) for i in range(n)]
+    acc = prims[-1]
+    for i in range(n - 2, -1, -1):
+        acc = t.op(UNION if i % 3 else SUBTRACTION, prims[i], acc)
+    return t.nodes, acc
+
+
+SCENES = {"g1": g1, "g8": g8, "g32": g32, "g64": g64, "g32_balanced": g32_balanced}
+
+# (events for OrbitCameraController::update) still camera of SURVEY 8(d): Orbit([35,-25])
+STILL_CAMERA_EVENTS = [(1, 35.0, -25.0)]
+LIMITS = {"g1": (0.01, 100.0, 64), "g8": (0.01, 100.0, 128), "g32": (0.01, 100.0, 256),
+          "g64": (0.01, 100.0, 512), "g32_balanced": (0.01, 100.0, 256)}
