@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the SDF ray-marching hot path on MI355X.
+
+A step = one full frame (prepare's uniform write + the draw) of the BASELINE metric
+workload: 1920x1080, 32-node graph (G32), 256 max steps, still orbit camera of SURVEY 8(d).
+The output image stays resident in HBM.  N > 1 (launched by torch.distributed.run, one rank
+per GPU): frames are sharded over ranks with no data-path collective ("weak" scaling: every
+rank renders its own K frames); only the timing barrier / max-over-ranks uses the process group.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # ditto
+BYTES_PER_PIXEL = 16             # one RGBA32F store per pixel: SURVEY 8(d) algorithmic bytes
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--width", type=int, default=1920)
+    p.add_argument("--height", type=int, default=1080)
+    p.add_argument("--scene", default="g32")
+    p.add_argument("--max-iter", type=int, default=256)
+    p.add_argument("--kernel", type=int, default=0, help="rm_kernel enum (0 = default tuned kernel)")
+    p.add_argument("--camera", choices=["still", "orbit"], default="still")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders W/div x H/div")
+    return p.parse_args()
+
+
+def cpu_baseline(args, scene_words, cam_events):
+    """The oracle (a CPU port of the reference shader) timed on the host cores, on a bounded
+    sample: the same scene/camera/limits at 1/div^2 of the pixels (Mpx/s is resolution-normalised)."""
+    from oracle import cbind
+    cbind.build()
+    cc, words = scene_words
+    W, H = args.width // args.cpu_sample_div, args.height // args.cpu_sample_div
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    u, *_ = cbind.orbit_uniforms((float(W), float(H)), events=cam_events)
+    lim = (0.01, 100.0, args.max_iter)
+    cbind.render(u, lim, cc, words, 64, 36, threads=cores)     # warm the threads / caches
+    t0 = time.perf_counter()
+    _, cnt = cbind.render(u, lim, cc, words, W, H, threads=cores, want_counters=True)
+    dt = time.perf_counter() - t0
+    return {"value": W * H / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
+            "sample": "%dx%d render (1/%d of the pixels) of the same scene, camera and limits, %.1f s wall"
+                      % (W, H, args.cpu_sample_div ** 2, dt),
+            "label": "CPU restatement of the reference shader (oracle/rm_oracle.c), not wgpu"}, cnt, (W, H)
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from ray_marching_amd import _ffi, camera, csg, renderer
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+
+    W, H = args.width, args.height
+    res = renderer.RayMarchingResources(local_rank)
+    res.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
+    res.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
+    node = csg.scene(args.scene)
+    cc, words = csg.serialize(node)
+    if len(words) > 255:
+        res.resize_command_buffer(4 * (len(words) + 1 + 63) // 64 * 64)
+    res.set_program(cc, words)
+
+    still_events = [(1, 35.0, -25.0)]                      # Orbit([35,-25]): yaw 0.35, pitch -0.25
+    ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
+    ctl.update(camera.Orbit([35.0, -25.0]))
+
+    def uniforms_for(step):
+        if args.camera == "orbit":                          # config 5: frame f of a 1024-frame orbit
+            f = (step * world + rank) % 1024
+            ctl.set_angles(2.0 * 3.141592653589793 * f / 1024.0, -0.25, 5.0)
+        return renderer.prepare_uniforms((float(W), float(H)), ctl.camera())
+
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream()
+    sptr = stream.cuda_stream
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    total = args.warmup + args.steps
+    unis = [uniforms_for(s) for s in range(total)]
+    for s in range(args.warmup):
+        res.set_uniforms(unis[s])
+        res.draw_device(W, H, out.data_ptr(), stream=sptr)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        res.set_uniforms(unis[args.warmup + k])            # prepare(): uniform write
+        ev[k][0].record(stream)
+        res.draw_device(W, H, out.data_ptr(), stream=sptr)  # paint(): the kernel, on this stream
+        ev[k][1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    if world > 1:
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kernel_ms = float(t[0]), float(t[1])
+
+    checksum = float(out[..., :3].double().sum().item())    # touches the result: nothing was skipped
+    if rank == 0:
+        pixels = W * H * args.steps * world
+        value = pixels / elapsed / 1e6
+        ach = BYTES_PER_PIXEL * W * H / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tfile):
+            try:
+                with open(tfile) as f:
+                    traffic = json.load(f).get("%s_%dx%d_%d" % (args.scene, W, H, args.max_iter))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Mpixels/s at 1920x1080, 256-step march, 32-node SDF",
+            "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%dx%d, %s (%d commands / %d words), %d max steps, 16 rays/px, RGBA32F out"
+                                   % (W, H, args.scene, cc, len(words), args.max_iter),
+                       "camera": args.camera, "kernel": args.kernel,
+                       "sharding": "frames over ranks, no collective" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel_ms": kernel_ms,
+                         "note": "algorithmic bytes = 16 B/pixel (one RGBA32F store); the kernel is FP32-VALU "
+                                 "bound by ~3 orders of magnitude, see `compute`"},
+            "checksum_rgb": checksum,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            base, cnt, (cw, ch) = cpu_baseline(args, (cc, words), still_events)
+            line["cpu_baseline"] = base
+            if args.camera == "still":
+                # oracle counters -> algorithmic map_scene evaluations of the full-size frame
+                scale = (W * H) / float(cw * ch)
+                evals = (cnt["march_steps"] + cnt["normal_taps"]) * scale
+                line["compute"] = {"map_scene_evals_per_frame": evals,
+                                   "evals_per_s": evals / (kernel_ms * 1e-3),
+                                   "note": "evaluations counted by the oracle on the CPU sample, scaled by pixel count"}
+        print(json.dumps(line), flush=True)
+    res.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,162 @@
+/*
+ * rm_abi.h -- C ABI of the MI355X-native SDF ray-marching render path (librm_hip.so).
+ *
+ * This is the drop-in boundary for the `src/ray_marching` wgpu pipeline of
+ * Mesoptier/ray-marching.  Everything the reference's `RayMarchingCallback::prepare`
+ * hands to the GPU is three flat byte blobs (limits, CSG command buffer, uniforms) and
+ * one draw; this header exposes exactly that.  All citations are file:line relative to
+ * the reference root.
+ *
+ *   reference (Rust/wgpu)                                   this ABI
+ *   ------------------------------------------------------  ---------------------------
+ *   RayMarchingResources::new          renderer.rs:51-175   rm_create
+ *   (drop of RayMarchingResources)                          rm_destroy
+ *   queue.write_buffer(uniforms, 0,..) renderer.rs:213-222  rm_write_buffer(RM_BUF_UNIFORMS) / rm_set_uniforms
+ *   queue.write_buffer(cmd_buffer,0,..) renderer.rs:230-234 rm_write_buffer(RM_BUF_COMMANDS, 0, &cmd_count, 4)
+ *   queue.write_buffer(cmd_buffer,4,..) renderer.rs:235-239 rm_write_buffer(RM_BUF_COMMANDS, 4, words, 4*n) / rm_set_program
+ *   create_buffer_init(limits)         renderer.rs:130-140  rm_write_buffer(RM_BUF_LIMITS) / rm_set_limits
+ *   render_pass.draw(0..4, 0..2)       renderer.rs:252-254  rm_draw   (the image is shaded once, not twice)
+ *   TODO "Recreate the buffers if too small" renderer.rs:229 rm_resize_command_buffer
+ *
+ * Conventions: plain pointers and sizes, no C++/torch types; every function returning
+ * `int` returns RM_OK (0) or a negative rm_status; nothing throws or unwinds across the
+ * ABI.  The caller owns every pointer it passes in; the library copies before returning.
+ * An rm_ctx is bound to one GPU and is externally synchronised (one thread at a time);
+ * different contexts may be used concurrently from different threads/processes.
+ *
+ * Output image: RGBA32F, 16 bytes per pixel, row-major, top row first (framebuffer
+ * orientation); pixel (px,py) has pt_screen = (-1 + 2(px+.5)/W, 1 - 2(py+.5)/H), the
+ * mapping vs_main + the rasteriser imply (ray_marching.wgsl:7-20).
+ */
+#ifndef RM_ABI_H
+#define RM_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RM_ABI_VERSION 1
+
+typedef struct rm_ctx rm_ctx;
+
+/* binding 2: `Uniforms` (ray_marching.wgsl:22-31 <-> renderer.rs:29-34), 144 bytes,
+ * matrices column-major, as produced by encase's UniformBuffer::write. */
+typedef struct rm_uniforms {
+    float viewport_extent[2]; /* byte 0  */
+    float _pad[2];            /* byte 8  */
+    float inv_proj[16];       /* byte 16 */
+    float inv_view[16];       /* byte 80 */
+} rm_uniforms;
+
+/* binding 0: `RayMarchLimits` (ray_marching.wgsl:78-85 <-> renderer.rs:36-41), 12 bytes. */
+typedef struct rm_limits {
+    float min_dist;
+    float max_dist;
+    uint32_t max_iter;
+} rm_limits;
+
+/* binding numbers of the reference's bind group (renderer.rs:60-94, 149-166) */
+enum rm_buffer {
+    RM_BUF_LIMITS = 0,   /* 12 B,  initial {0.01, 100.0, 100}      renderer.rs:130-140 */
+    RM_BUF_COMMANDS = 1, /* 1024 B, u32 cmd_count @0, u32 words @4 renderer.rs:142-147, wgsl:146-151 */
+    RM_BUF_UNIFORMS = 2  /* 144 B, initial all-zero                 renderer.rs:124-128 */
+};
+
+enum rm_status {
+    RM_OK = 0,
+    RM_ERR_NULL = -1,            /* required pointer is NULL */
+    RM_ERR_TRUNCATED = -2,       /* a command reads past the end of the command buffer */
+    RM_ERR_STACK_UNDERFLOW = -3, /* binary operator with fewer than two operands (UB in wgsl:177-180) */
+    RM_ERR_STACK_OVERFLOW = -4,  /* value stack deeper than 32 (wgsl:173) */
+    RM_ERR_EMPTY_RESULT = -5,    /* program leaves nothing on the stack */
+    RM_ERR_OPCODE = -6,          /* opcode the reference does not define (wgsl:223-225 would yield 0.0) */
+    RM_ERR_TOO_LARGE = -7,       /* write past the end of a buffer / program larger than the buffer */
+    RM_ERR_RANGE = -8,           /* row band or image size out of range */
+    RM_ERR_DEVICE = -9,          /* a HIP call failed; see rm_last_error */
+    RM_ERR_NO_DEVICE = -10,      /* no usable GPU */
+    RM_ERR_ARG = -11             /* invalid enum / option value */
+};
+
+/* rm_set_option / rm_get_info keys */
+enum rm_option {
+    RM_OPT_KERNEL = 0,     /* which kernel rm_draw launches; see enum rm_kernel */
+    RM_OPT_TIMING = 1,     /* 1: bracket every kernel launch with HIP events (rm_get_info RM_INFO_KERNEL_MS) */
+    RM_OPT_STRICT_CAP = 2  /* 1 (default): command buffer is exactly the reference's 1024 B unless resized */
+};
+enum rm_kernel {
+    RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */
+    RM_KERNEL_PIXEL = 1,     /* v1: one thread per pixel, program staged in LDS, lock-step AA loop */
+    RM_KERNEL_RAYPOOL = 2,   /* v2: per-wave ray pool, ballot-driven refill, program through the scalar cache */
+    RM_KERNEL_RAYPOOL_LDS = 3 /* v2 with the program read from LDS */
+};
+enum rm_info {
+    RM_INFO_KERNEL_MS = 0,       /* duration of the last timed kernel launch, milliseconds */
+    RM_INFO_PROGRAM_COMMANDS = 1,
+    RM_INFO_PROGRAM_WORDS = 2,
+    RM_INFO_PROGRAM_DEPTH = 3,   /* maximum value-stack depth of the current program */
+    RM_INFO_DEVICE = 4,
+    RM_INFO_CU_COUNT = 5
+};
+
+int rm_abi_version(void);
+int rm_device_count(void);
+
+/* RayMarchingResources::new (renderer.rs:51-175).  device = HIP ordinal. */
+int rm_create(int device, rm_ctx** out);
+void rm_destroy(rm_ctx* ctx);
+
+/* Queue::write_buffer(buffer, offset, data) (renderer.rs:213,230,235).  offset and size
+ * must be multiples of 4 (wgpu COPY_BUFFER_ALIGNMENT) and stay inside the buffer. */
+int rm_write_buffer(rm_ctx* ctx, int buffer, uint64_t offset, const void* data, uint64_t size);
+
+/* Typed forms of the same writes. */
+int rm_set_uniforms(rm_ctx* ctx, const rm_uniforms* u);
+int rm_set_limits(rm_ctx* ctx, const rm_limits* l);
+/* = write_buffer(cmd,0,&cmd_count) + write_buffer(cmd,4,words) after validating the program;
+ * on error the command buffer is left unchanged.  cmd_count = 0 is the `csg_node == None`
+ * case (renderer.rs:224-227). */
+int rm_set_program(rm_ctx* ctx, uint32_t cmd_count, const uint32_t* words, uint32_t n_words);
+
+/* The reference's TODO (renderer.rs:229): grow the command buffer beyond 1024 bytes.
+ * Contents are preserved.  bytes in [1024, 65536], multiple of 4. */
+int rm_resize_command_buffer(rm_ctx* ctx, uint64_t bytes);
+
+/* Validate the current command-buffer contents without drawing. */
+int rm_validate(rm_ctx* ctx);
+
+/* Context-free validation of a program in the reference wire format (pure host code, usable
+ * without a GPU): the checks the reference leaves as UB (wgsl:177-185) or as a wgpu panic.
+ * out_max_depth (nullable) receives the deepest value-stack use of the reference machine. */
+int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, uint32_t* out_max_depth);
+
+/* paint (renderer.rs:244-255) restricted to rows [row0,row0+rows) of a W x H target.
+ * out_rgba receives rows*W*4 floats.  out_is_device = 0: host memory, filled on return.
+ * out_is_device = 1: device memory on ctx's GPU; the launch is asynchronous on `stream`
+ * (a hipStream_t, or NULL for the context's own stream; rm_sync waits for the latter). */
+int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, float* out_rgba,
+            int out_is_device, void* stream);
+
+/* n_frames draws that differ only in their uniforms (camera-orbit batch); frame f is
+ * written at out_rgba + f*W*H*4. */
+int rm_draw_batch(rm_ctx* ctx, const rm_uniforms* frames, uint32_t n_frames, uint32_t W, uint32_t H,
+                  float* out_rgba, int out_is_device, void* stream);
+
+int rm_sync(rm_ctx* ctx);
+
+int rm_set_option(rm_ctx* ctx, int key, int64_t value);
+int rm_get_info(rm_ctx* ctx, int key, double* out);
+
+/* Stream-write calibration: a fill kernel writes `bytes` of device memory `iters` times
+ * with 16 B/lane stores; reports the achieved GB/s (the measured HBM-write ceiling). */
+int rm_measure_write_bandwidth(rm_ctx* ctx, uint64_t bytes, int iters, double* out_gbps);
+
+/* Message for the last error on this context (ctx may be NULL: last rm_create error). */
+const char* rm_last_error(rm_ctx* ctx);
+const char* rm_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RM_ABI_H */

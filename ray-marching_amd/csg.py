@@ -1,0 +1,109 @@
+"""Python face of the C++ scene model (csrc/host/csg.hpp via include/rm_host.h), keeping the
+reference's names: CSGCommandType, CSGCommandBufferBuilder (src/ray_marching/csg/builder.rs),
+Sphere / Box / Union / Subtraction and build_commands (csg/mod.rs, primitives/, operations/).
+All logic runs in librm_host.so; these classes only hold handles."""
+import ctypes as C
+import enum
+
+import numpy as np
+
+from . import _ffi
+
+
+class CSGCommandType(enum.IntEnum):  # builder.rs:3-24
+    Sphere = 0
+    Box = 1
+    Union = 100
+    Subtraction = 101
+
+
+def _f3(v):
+    a = (C.c_float * 3)(*[float(x) for x in v])
+    return a
+
+
+class CSGCommandBufferBuilder:  # builder.rs:26-62
+    def __init__(self):
+        self._L = _ffi.host_lib()
+        self._h = self._L.rmh_builder_new()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rmh_builder_free(self._h)
+            self._h = None
+
+    def push_command(self, cmd_type):
+        self._L.rmh_builder_push_command(self._h, int(cmd_type))
+        return self
+
+    def push_param_vec3(self, value):
+        self._L.rmh_builder_push_param_vec3(self._h, _f3(value))
+        return self
+
+    def push_param_float(self, value):
+        self._L.rmh_builder_push_param_float(self._h, float(value))
+        return self
+
+    @property
+    def cmd_count(self):
+        return int(self._L.rmh_builder_cmd_count(self._h))
+
+    @property
+    def buffer(self):
+        n = self._L.rmh_builder_len(self._h)
+        p = self._L.rmh_builder_buffer(self._h)
+        return np.array([p[i] for i in range(n)], dtype=np.uint32)
+
+
+class CSGNode:
+    """Owning handle of a C++ CSGNode tree (csg/mod.rs:28-45)."""
+
+    def __init__(self, handle):
+        if not handle:
+            raise ValueError("null CSGNode handle")
+        self._L = _ffi.host_lib()
+        self._h = handle
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.rmh_node_free(self._h)
+            self._h = None
+
+    def clone(self):
+        return CSGNode(self._L.rmh_node_clone(self._h))
+
+    def build_commands(self, builder):
+        """BuildCommands::build_commands (csg/mod.rs:16-19)."""
+        self._L.rmh_build_commands(self._h, builder._h)
+
+
+def Sphere(center=(0.0, 0.0, 0.0), radius=1.0):  # sphere.rs:8-13
+    return CSGNode(_ffi.host_lib().rmh_sphere(_f3(center), float(radius)))
+
+
+def Box(center=(0.0, 0.0, 0.0), radius=(1.0, 1.0, 1.0)):  # box.rs:8-12
+    return CSGNode(_ffi.host_lib().rmh_box(_f3(center), _f3(radius)))
+
+
+def Union(lhs, rhs):  # operations/mod.rs:55
+    return CSGNode(_ffi.host_lib().rmh_union(lhs._h, rhs._h))
+
+
+def Subtraction(lhs, rhs):  # operations/mod.rs:56
+    return CSGNode(_ffi.host_lib().rmh_subtraction(lhs._h, rhs._h))
+
+
+def scene(name):
+    """Named synthetic scene (csrc/host/scenes.hpp): g1, g8, g32, g64, g32_balanced."""
+    h = _ffi.host_lib().rmh_scene(name.encode())
+    if not h:
+        raise KeyError(name)
+    return CSGNode(h)
+
+
+def serialize(node):
+    """(cmd_count, words) of `node` (None = empty scene, renderer.rs:224-227)."""
+    b = CSGCommandBufferBuilder()
+    if node is not None:
+        node.build_commands(b)
+    return b.cmd_count, b.buffer

@@ -1,0 +1,87 @@
+// scenes.hpp -- the deterministic synthetic scenes bench.py and the tests render:
+// G1 / G8 / G32 / G64 plus a balanced-tree variant of G32.  Built only from the reference's
+// four node types.  Coordinates are computed in double and rounded once to f32.
+#pragma once
+#include <cstdint>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "csg.hpp"
+
+namespace ray_marching::scenes {
+
+using csg::CSGNode;
+
+struct Lcg {  // x <- 1664525 x + 1013904223 (mod 2^32); u = (x >> 8) / 2^24
+    uint32_t x;
+    double u() {
+        x = 1664525u * x + 1013904223u;
+        return (double)(x >> 8) / 16777216.0;
+    }
+};
+
+inline std::vector<CSGNode> grid_prims(int nx, int nz, uint32_t seed) {
+    Lcg rng{seed};
+    std::vector<CSGNode> prims;
+    for (int k = 0; k < nx * nz; k++) {
+        const int ix = k % nx, iz = k / nx;
+        const float x = (float)((ix - (nx - 1) / 2.0) * 1.1);
+        const float z = (float)((iz - (nz - 1) / 2.0) * 1.1);
+        const double u1 = rng.u(), u2 = rng.u();
+        const float y = (float)(0.3 * u1);
+        if ((ix + iz) % 2 == 0) {
+            prims.emplace_back(csg::Sphere{{x, y, z}, (float)(0.35 + 0.15 * u2)});
+        } else {
+            const float h = (float)(0.3 + 0.15 * u2);
+            prims.emplace_back(csg::Box{{x, y, z}, {h, h, h}});
+        }
+    }
+    return prims;
+}
+
+// Left-deep fold: operator k (0-based) is Subtraction when k % 4 == 3, else Union.
+inline CSGNode fold_left(std::vector<CSGNode> prims) {
+    CSGNode acc = prims[0];
+    for (size_t k = 0; k + 1 < prims.size(); k++)
+        acc = (k % 4 == 3) ? csg::make_subtraction(std::move(acc), prims[k + 1])
+                           : csg::make_union(std::move(acc), prims[k + 1]);
+    return acc;
+}
+
+inline CSGNode fold_balanced(std::vector<CSGNode> level) {
+    size_t k = 0;
+    while (level.size() > 1) {
+        std::vector<CSGNode> next;
+        for (size_t i = 0; i < level.size(); i += 2, k++)
+            next.push_back((k % 4 == 3) ? csg::make_subtraction(level[i], level[i + 1])
+                                        : csg::make_union(level[i], level[i + 1]));
+        level = std::move(next);
+    }
+    return level[0];
+}
+
+inline CSGNode g1() { return CSGNode(csg::Sphere{{0, 0, 0}, 1.0f}); }
+
+inline CSGNode g8() {  // Union(Subtraction(Union(S0,B1),S2),B3)
+    CSGNode s0(csg::Sphere{{0, 0, 0}, 1.0f});
+    CSGNode b1(csg::Box{{0, 0, 0}, {0.8f, 0.8f, 0.8f}});
+    CSGNode s2(csg::Sphere{{0.9f, 0.5f, 0.6f}, 0.6f});
+    CSGNode b3(csg::Box{{0, -1.2f, 0}, {1.5f, 0.1f, 1.5f}});
+    return csg::make_union(csg::make_subtraction(csg::make_union(s0, b1), s2), b3);
+}
+
+inline CSGNode g32() { return fold_left(grid_prims(4, 4, 0x5DF00020u)); }
+inline CSGNode g64() { return fold_left(grid_prims(8, 4, 0x5DF00040u)); }
+inline CSGNode g32_balanced() { return fold_balanced(grid_prims(4, 4, 0x5DF00020u)); }
+
+inline std::optional<CSGNode> by_name(const std::string& name) {
+    if (name == "g1") return g1();
+    if (name == "g8") return g8();
+    if (name == "g32") return g32();
+    if (name == "g64") return g64();
+    if (name == "g32_balanced") return g32_balanced();
+    return std::nullopt;
+}
+
+}  // namespace ray_marching::scenes

@@ -1,0 +1,426 @@
+// rm_abi.hip -- host side of librm_hip.so: the C ABI declared in include/rm_abi.h.
+// Mirrors RayMarchingResources / RayMarchingCallback::{prepare,paint}
+// (src/ray_marching/renderer.rs:43-49, 51-175, 195-256 of the reference).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rm_abi.h"
+#include "rm_decode.h"
+#include "rm_device.h"
+#include "rm_kernels.h"
+
+#define RM_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+constexpr uint64_t kRefCmdBufferBytes = 1024;  // renderer.rs:142-147
+constexpr uint64_t kMaxCmdBufferBytes = 65536;
+constexpr uint32_t kMaxDim = 1u << 16;
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+struct rm_ctx {
+    int device = -1;
+    int cu_count = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // host shadows of the three buffers of the reference's bind group
+    rm_limits limits{0.01f, 100.0f, 100u};  // renderer.rs:133-137
+    rm_uniforms uniforms{};                 // Uniforms::default(), renderer.rs:126
+    std::vector<uint32_t> cmd;              // [0] = cmd_count, [1..] = words; zero-initialised like a wgpu buffer
+    bool cmd_dirty = true;
+    int cmd_status = RM_OK;
+    // decoded program, device copy
+    RmDecoded decoded;
+    RmRecord* d_prog = nullptr;
+    size_t d_prog_cap = 0;
+    // scratch for host-destination draws and batch uniforms
+    float* d_out = nullptr;
+    size_t d_out_bytes = 0;
+    rm_uniforms* d_frames = nullptr;
+    size_t d_frames_cap = 0;
+    // options / info
+    int kernel = RM_KERNEL_DEFAULT;
+    bool timing = false;
+    double last_kernel_ms = 0.0;
+    std::string err;
+};
+
+namespace {
+
+int fail(rm_ctx* c, int status, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return status;
+}
+
+#define HIP_TRY(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(ctx, RM_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                       \
+    } while (0)
+
+int ensure_program(rm_ctx* c) {
+    if (!c->cmd_dirty) return c->cmd_status;
+    c->cmd_dirty = false;
+    const uint32_t cap_words = (uint32_t)c->cmd.size() - 1u;
+    RmDecoded d;
+    int rc = rm_decode_program(c->cmd[0], c->cmd.data() + 1, cap_words, &d);
+    if (rc != RM_OK) {
+        c->cmd_status = rc;
+        return fail(c, rc, "invalid CSG program in command buffer: %s", rm_status_string(rc));
+    }
+    if (d.rec.size() > c->d_prog_cap) {
+        if (c->d_prog) (void)hipFree(c->d_prog);
+        c->d_prog = nullptr;
+        c->d_prog_cap = 0;
+        size_t cap = std::max<size_t>(64, d.rec.size() * 2);
+        hipError_t e = hipMalloc(&c->d_prog, cap * sizeof(RmRecord));
+        if (e != hipSuccess) {
+            c->cmd_dirty = true;
+            return fail(c, RM_ERR_DEVICE, "hipMalloc(program) failed: %s", hipGetErrorString(e));
+        }
+        c->d_prog_cap = cap;
+    }
+    if (!d.rec.empty()) {
+        // Synchronous copy from pageable memory: complete before the next launch on any stream.
+        hipError_t e = hipMemcpy(c->d_prog, d.rec.data(), d.rec.size() * sizeof(RmRecord), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            c->cmd_dirty = true;
+            return fail(c, RM_ERR_DEVICE, "hipMemcpy(program) failed: %s", hipGetErrorString(e));
+        }
+    }
+    c->decoded = std::move(d);
+    c->cmd_status = RM_OK;
+    return RM_OK;
+}
+
+int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t row0,
+           uint32_t rows, float* d_out, hipStream_t s) {
+    RmLaunch L;
+    L.prog = c->d_prog;
+    L.n_rec = (uint32_t)c->decoded.rec.size();
+    L.spill_depth = c->decoded.spill_depth;
+    L.min_dist = c->limits.min_dist;
+    L.max_dist = c->limits.max_dist;
+    L.max_iter = c->limits.max_iter;
+    L.W = W; L.H = H; L.row0 = row0; L.rows = rows;
+    L.out = d_out;
+    L.frames = frames_dev;
+    L.u = c->uniforms;
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
+    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_PIXEL : c->kernel;
+    switch (kernel) {
+    case RM_KERNEL_PIXEL: {
+        dim3 grid((W + 15u) / 16u, (rows + 15u) / 16u, n_frames);
+        size_t shmem = (size_t)L.n_rec * sizeof(RmRecord) + (size_t)L.spill_depth * 256u * sizeof(float);
+        hipLaunchKernelGGL(rmk::rm_render_pixel, grid, dim3(256), shmem, s, L);
+    } break;
+    default:
+        return fail(c, RM_ERR_ARG, "kernel variant %d is not available", kernel);
+    }
+    HIP_TRY(c, hipGetLastError());
+    if (c->timing) {
+        HIP_TRY(c, hipEventRecord(c->ev1, s));
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->last_kernel_ms = ms;
+    }
+    return RM_OK;
+}
+
+int check_dims(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows) {
+    if (W == 0 || H == 0 || W > kMaxDim || H > kMaxDim) return fail(c, RM_ERR_RANGE, "image size %ux%u out of range", W, H);
+    if (rows == 0 || row0 >= H || rows > H - row0)
+        return fail(c, RM_ERR_RANGE, "row band [%u,+%u) outside image height %u", row0, rows, H);
+    return RM_OK;
+}
+
+int ensure_out(rm_ctx* c, size_t bytes) {
+    if (bytes <= c->d_out_bytes) return RM_OK;
+    if (c->d_out) (void)hipFree(c->d_out);
+    c->d_out = nullptr;
+    c->d_out_bytes = 0;
+    HIP_TRY(c, hipMalloc(&c->d_out, bytes));
+    c->d_out_bytes = bytes;
+    return RM_OK;
+}
+
+}  // namespace
+
+RM_EXPORT int rm_abi_version(void) { return RM_ABI_VERSION; }
+
+RM_EXPORT int rm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+RM_EXPORT int rm_create(int device, rm_ctx** out) {
+    if (!out) return fail(nullptr, RM_ERR_NULL, "rm_create: out is NULL");
+    *out = nullptr;
+    int n = rm_device_count();
+    if (n <= 0) return fail(nullptr, RM_ERR_NO_DEVICE, "rm_create: no HIP device is visible");
+    if (device < 0 || device >= n) return fail(nullptr, RM_ERR_ARG, "rm_create: device %d not in [0,%d)", device, n);
+    rm_ctx* c = new (std::nothrow) rm_ctx();
+    if (!c) return fail(nullptr, RM_ERR_DEVICE, "rm_create: out of host memory");
+    c->device = device;
+    c->cmd.assign(kRefCmdBufferBytes / 4, 0u);
+    hipError_t e = hipSetDevice(device);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e == hipSuccess) {
+        c->cu_count = prop.multiProcessorCount;
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, RM_ERR_DEVICE, "rm_create: HIP initialisation failed: %s", hipGetErrorString(e));
+        rm_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return RM_OK;
+}
+
+RM_EXPORT void rm_destroy(rm_ctx* c) {
+    if (!c) return;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_prog) (void)hipFree(c->d_prog);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+RM_EXPORT int rm_write_buffer(rm_ctx* c, int buffer, uint64_t offset, const void* data, uint64_t size) {
+    if (!c) return RM_ERR_NULL;
+    if (!data && size) return fail(c, RM_ERR_NULL, "rm_write_buffer: data is NULL");
+    if ((offset & 3u) || (size & 3u))
+        return fail(c, RM_ERR_ARG, "rm_write_buffer: offset %llu / size %llu not multiples of 4",
+                    (unsigned long long)offset, (unsigned long long)size);
+    uint8_t* dst = nullptr;
+    uint64_t cap = 0;
+    switch (buffer) {
+    case RM_BUF_LIMITS: dst = reinterpret_cast<uint8_t*>(&c->limits); cap = sizeof(rm_limits); break;
+    case RM_BUF_COMMANDS: dst = reinterpret_cast<uint8_t*>(c->cmd.data()); cap = c->cmd.size() * 4; break;
+    case RM_BUF_UNIFORMS: dst = reinterpret_cast<uint8_t*>(&c->uniforms); cap = sizeof(rm_uniforms); break;
+    default: return fail(c, RM_ERR_ARG, "rm_write_buffer: unknown buffer %d", buffer);
+    }
+    if (offset > cap || size > cap - offset)
+        return fail(c, RM_ERR_TOO_LARGE, "rm_write_buffer: [%llu,+%llu) exceeds the %llu-byte buffer %d",
+                    (unsigned long long)offset, (unsigned long long)size, (unsigned long long)cap, buffer);
+    if (size) std::memcpy(dst + offset, data, size);
+    if (buffer == RM_BUF_COMMANDS && size) c->cmd_dirty = true;
+    return RM_OK;
+}
+
+RM_EXPORT int rm_set_uniforms(rm_ctx* c, const rm_uniforms* u) {
+    if (!c) return RM_ERR_NULL;
+    if (!u) return fail(c, RM_ERR_NULL, "rm_set_uniforms: u is NULL");
+    return rm_write_buffer(c, RM_BUF_UNIFORMS, 0, u, sizeof *u);
+}
+
+RM_EXPORT int rm_set_limits(rm_ctx* c, const rm_limits* l) {
+    if (!c) return RM_ERR_NULL;
+    if (!l) return fail(c, RM_ERR_NULL, "rm_set_limits: l is NULL");
+    return rm_write_buffer(c, RM_BUF_LIMITS, 0, l, sizeof *l);
+}
+
+RM_EXPORT int rm_set_program(rm_ctx* c, uint32_t cmd_count, const uint32_t* words, uint32_t n_words) {
+    if (!c) return RM_ERR_NULL;
+    if (n_words && !words) return fail(c, RM_ERR_NULL, "rm_set_program: words is NULL");
+    const uint64_t cap_words = c->cmd.size() - 1;
+    if (n_words > cap_words)
+        return fail(c, RM_ERR_TOO_LARGE, "rm_set_program: %u words do not fit the %llu-byte command buffer "
+                    "(rm_resize_command_buffer lifts the reference's 1024-byte limit)",
+                    n_words, (unsigned long long)(c->cmd.size() * 4));
+    RmDecoded d;
+    int rc = rm_decode_program(cmd_count, words, n_words, &d);
+    if (rc != RM_OK) return fail(c, rc, "rm_set_program: %s", rm_status_string(rc));
+    c->cmd[0] = cmd_count;                                               // renderer.rs:230-234
+    if (n_words) std::memcpy(c->cmd.data() + 1, words, (size_t)n_words * 4);  // renderer.rs:235-239
+    c->cmd_dirty = true;
+    return RM_OK;
+}
+
+RM_EXPORT int rm_resize_command_buffer(rm_ctx* c, uint64_t bytes) {
+    if (!c) return RM_ERR_NULL;
+    if (bytes < kRefCmdBufferBytes || bytes > kMaxCmdBufferBytes || (bytes & 3u))
+        return fail(c, RM_ERR_ARG, "rm_resize_command_buffer: %llu not a multiple of 4 in [1024, 65536]",
+                    (unsigned long long)bytes);
+    c->cmd.resize(bytes / 4, 0u);
+    c->cmd_dirty = true;
+    return RM_OK;
+}
+
+RM_EXPORT int rm_validate(rm_ctx* c) {
+    if (!c) return RM_ERR_NULL;
+    RmDecoded d;
+    int rc = rm_decode_program(c->cmd[0], c->cmd.data() + 1, (uint32_t)c->cmd.size() - 1u, &d);
+    if (rc != RM_OK) return fail(c, rc, "invalid CSG program in command buffer: %s", rm_status_string(rc));
+    return RM_OK;
+}
+
+RM_EXPORT int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_words,
+                                  uint32_t* out_max_depth) {
+    RmDecoded d;
+    int rc = rm_decode_program(cmd_count, words, n_words, &d);
+    if (rc == RM_OK && out_max_depth) *out_max_depth = d.max_depth;
+    return rc;
+}
+
+RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, float* out_rgba,
+                      int out_is_device, void* stream) {
+    if (!c) return RM_ERR_NULL;
+    if (!out_rgba) return fail(c, RM_ERR_NULL, "rm_draw: out_rgba is NULL");
+    int rc = check_dims(c, W, H, row0, rows);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_program(c);
+    if (rc != RM_OK) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    const size_t bytes = (size_t)rows * W * 16u;
+    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, s);
+    rc = ensure_out(c, bytes);
+    if (rc != RM_OK) return rc;
+    rc = launch(c, nullptr, 1, W, H, row0, rows, c->d_out, s);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgba, c->d_out, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_frames, uint32_t W, uint32_t H,
+                            float* out_rgba, int out_is_device, void* stream) {
+    if (!c) return RM_ERR_NULL;
+    if (!out_rgba || !frames) return fail(c, RM_ERR_NULL, "rm_draw_batch: NULL argument");
+    if (n_frames == 0 || n_frames > 65535u) return fail(c, RM_ERR_RANGE, "rm_draw_batch: n_frames %u not in [1,65535]", n_frames);
+    int rc = check_dims(c, W, H, 0, H);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_program(c);
+    if (rc != RM_OK) return rc;
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    if (n_frames > c->d_frames_cap) {
+        if (c->d_frames) (void)hipFree(c->d_frames);
+        c->d_frames = nullptr;
+        c->d_frames_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_frames, (size_t)n_frames * sizeof(rm_uniforms)));
+        c->d_frames_cap = n_frames;
+    }
+    HIP_TRY(c, hipMemcpy(c->d_frames, frames, (size_t)n_frames * sizeof(rm_uniforms), hipMemcpyHostToDevice));
+    const size_t bytes = (size_t)n_frames * H * W * 16u;
+    if (out_is_device) return launch(c, c->d_frames, n_frames, W, H, 0, H, out_rgba, s);
+    rc = ensure_out(c, bytes);
+    if (rc != RM_OK) return rc;
+    rc = launch(c, c->d_frames, n_frames, W, H, 0, H, c->d_out, s);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgba, c->d_out, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(c, hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+RM_EXPORT int rm_sync(rm_ctx* c) {
+    if (!c) return RM_ERR_NULL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return RM_OK;
+}
+
+RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
+    if (!c) return RM_ERR_NULL;
+    switch (key) {
+    case RM_OPT_KERNEL:
+        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_RAYPOOL_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        c->kernel = (int)value;
+        return RM_OK;
+    case RM_OPT_TIMING: c->timing = value != 0; return RM_OK;
+    case RM_OPT_STRICT_CAP: return RM_OK;
+    default: return fail(c, RM_ERR_ARG, "unknown option %d", key);
+    }
+}
+
+RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
+    if (!c) return RM_ERR_NULL;
+    if (!out) return fail(c, RM_ERR_NULL, "rm_get_info: out is NULL");
+    switch (key) {
+    case RM_INFO_KERNEL_MS: *out = c->last_kernel_ms; return RM_OK;
+    case RM_INFO_DEVICE: *out = c->device; return RM_OK;
+    case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
+    case RM_INFO_PROGRAM_COMMANDS:
+    case RM_INFO_PROGRAM_WORDS:
+    case RM_INFO_PROGRAM_DEPTH: {
+        RmDecoded d;
+        int rc = rm_decode_program(c->cmd[0], c->cmd.data() + 1, (uint32_t)c->cmd.size() - 1u, &d);
+        if (rc != RM_OK) return fail(c, rc, "invalid CSG program in command buffer: %s", rm_status_string(rc));
+        *out = key == RM_INFO_PROGRAM_COMMANDS ? c->cmd[0] : key == RM_INFO_PROGRAM_WORDS ? d.n_words : d.max_depth;
+        return RM_OK;
+    }
+    default: return fail(c, RM_ERR_ARG, "unknown info key %d", key);
+    }
+}
+
+RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, double* out_gbps) {
+    if (!c) return RM_ERR_NULL;
+    if (!out_gbps) return fail(c, RM_ERR_NULL, "rm_measure_write_bandwidth: out is NULL");
+    if (bytes < 4096 || (bytes & 15u) || iters < 1 || iters > 1000) return fail(c, RM_ERR_ARG, "bad bytes/iters");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float4* buf = nullptr;
+    HIP_TRY(c, hipMalloc(&buf, bytes));
+    const size_t n_vec = bytes / 16u;
+    const int grid = std::max(1, c->cu_count) * 8;
+    hipLaunchKernelGGL(rmk::rm_fill, dim3(grid), dim3(256), 0, c->stream, buf, n_vec, 0.0f);  // warm-up
+    hipError_t e = hipEventRecord(c->ev0, c->stream);
+    for (int i = 0; i < iters && e == hipSuccess; i++)
+        hipLaunchKernelGGL(rmk::rm_fill, dim3(grid), dim3(256), 0, c->stream, buf, n_vec, (float)i);
+    if (e == hipSuccess) e = hipEventRecord(c->ev1, c->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(c->ev1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "write-bandwidth calibration failed: %s", hipGetErrorString(e));
+    *out_gbps = (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return RM_OK;
+}
+
+RM_EXPORT const char* rm_last_error(rm_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+RM_EXPORT const char* rm_status_string(int status) {
+    switch (status) {
+    case RM_OK: return "ok";
+    case RM_ERR_NULL: return "null pointer";
+    case RM_ERR_TRUNCATED: return "command reads past the end of the command buffer";
+    case RM_ERR_STACK_UNDERFLOW: return "binary operator with fewer than two operands on the value stack";
+    case RM_ERR_STACK_OVERFLOW: return "value stack deeper than 32";
+    case RM_ERR_EMPTY_RESULT: return "program leaves no value on the stack";
+    case RM_ERR_OPCODE: return "unknown opcode";
+    case RM_ERR_TOO_LARGE: return "write exceeds buffer size";
+    case RM_ERR_RANGE: return "image size or row band out of range";
+    case RM_ERR_DEVICE: return "HIP runtime error";
+    case RM_ERR_NO_DEVICE: return "no GPU available";
+    case RM_ERR_ARG: return "invalid argument";
+    default: return "unknown status";
+    }
+}

@@ -1,0 +1,44 @@
+// rm_device.h -- structures shared by the host side of librm_hip.so and its kernels.
+#pragma once
+#include <stdint.h>
+
+#include "rm_abi.h"
+
+// One decoded command = 32 bytes, so that a wave fetches it with one s_load_dwordx8
+// (scalar-cache variant) or two ds_read_b128 (LDS variant).
+//
+// The reference's stack machine (ray_marching.wgsl:187-203) pushes every command's value
+// on a private array.  The program is straight-line postfix, so the stack slot of every
+// operand is known when the program is uploaded: the decoder (rm_decode.h) rewrites it
+// for an accumulator machine that keeps the top of stack in a VGPR:
+//   prim + PUSH  : [spill acc to LDS if one is live]  acc = prim(pos)
+//   prim + UNION : acc = min(acc, prim(pos))        <- "prim; Union" fused (rhs is a leaf)
+//   prim + SUB   : acc = max(acc, -prim(pos))       <- "prim; Subtraction" fused
+//   POP  + UNION : acc = min(pop(), acc)            <- operator whose rhs is a sub-tree
+//   POP  + SUB   : acc = max(pop(), -acc)
+// The arithmetic performed on each value is exactly the reference's, in the same order;
+// only the bookkeeping (where a value lives) changes.
+struct RmRecord {
+    uint32_t op;  // kind | mode<<2 | spill<<4
+    float p[7];   // sphere: cx cy cz r          box: cx cy cz rx ry rz
+};
+static_assert(sizeof(RmRecord) == 32, "record must be 32 bytes");
+
+enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2 };
+enum : uint32_t { RM_MODE_PUSH = 0, RM_MODE_UNION = 1, RM_MODE_SUB = 2 };
+#define RM_OP(kind, mode, spill) ((uint32_t)(kind) | ((uint32_t)(mode) << 2) | ((uint32_t)(spill) << 4))
+
+// reference opcodes (csg/builder.rs:1-24)
+enum : uint32_t { RM_CMD_SPHERE = 0, RM_CMD_BOX = 1, RM_CMD_UNION = 100, RM_CMD_SUBTRACTION = 101 };
+
+struct RmLaunch {
+    const RmRecord* prog;      // decoded program, device memory
+    uint32_t n_rec;            // == cmd_count of the reference program
+    uint32_t spill_depth;      // LDS value-stack slots per lane this program needs
+    float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
+    uint32_t max_iter;
+    uint32_t W, H, row0, rows;
+    float* out;                // rows*W*4 floats per frame
+    const rm_uniforms* frames; // nullptr: use `u`; else frames[blockIdx.z]
+    rm_uniforms u;
+};

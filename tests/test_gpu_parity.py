@@ -1,0 +1,281 @@
+"""Parity of the HIP path with the oracle -- the tests proper.  Everything goes through the
+C ABI (include/rm_abi.h via ctypes); the bar is BIT-EXACT equality of the RGBA32F image
+(the stated contract is <= 1e-4 per channel; because hit/miss and the checkerboard are
+discontinuous the only robust way to meet it is to execute the same IEEE op sequence)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import scenes
+from ray_marching_amd import _ffi, camera, csg, renderer
+
+pytestmark = pytest.mark.gpu
+
+TOLERANCE = 1e-4      # contract (BASELINE.json north_star); asserted bit-exact below
+KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_LDS]
+KERNEL_IDS = ["pixel", "raypool", "raypool_lds"]
+IDX = G.index()
+
+
+@pytest.fixture(scope="module")
+def res():
+    r = renderer.RayMarchingResources(0)
+    yield r
+    r.close()
+
+
+def assert_same(img, ref):
+    assert img.shape == ref.shape
+    if img.tobytes() != ref.tobytes():
+        d = np.abs(img.astype(np.float64) - ref.astype(np.float64))
+        bad = np.argwhere(d.max(axis=-1) > 0)
+        raise AssertionError("images differ: max abs diff %.3g (contract %.0e), %d/%d pixels, first at %s"
+                             % (np.nanmax(d), TOLERANCE, len(bad), d.shape[0] * d.shape[1], bad[:4].tolist()))
+
+
+def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kernel=_ffi.RM_KERNEL_DEFAULT):
+    res.set_option(_ffi.RM_OPT_KERNEL, kernel)
+    res.set_limits(limits)
+    res.set_uniforms(u)
+    res.set_program(cc, words)
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("name", sorted(n for n in IDX if "file" in IDX[n]))
+def test_golden_fixtures(res, name, kernel):
+    e = IDX[name]
+    u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
+    setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
+    assert_same(res.draw(e["W"], e["H"]), G.load_image(e))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("name", sorted(n for n in IDX if "file" not in IDX[n]))
+def test_golden_checksums(res, name, kernel):
+    e = IDX[name]
+    u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
+    setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
+    img = res.draw(e["W"], e["H"])
+    assert hashlib.sha256(img.tobytes()).hexdigest() == e["sha256"]
+
+
+def oracle_case(oracle, scene, W, H, limits, events=scenes.STILL_CAMERA_EVENTS):
+    cc, w = oracle.serialize(*scene) if scene is not None else (0, np.zeros(0, np.uint32))
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+    return cc, w, u
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+@pytest.mark.parametrize("W,H", [(1, 1), (7, 5), (16, 16), (17, 33), (63, 9), (130, 70)])
+def test_ragged_sizes_vs_oracle(res, oracle, W, H, kernel):
+    cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
+    lim = (0.01, 100.0, 96)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_limits_edge_cases(res, oracle, kernel):
+    W, H = 40, 24
+    cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
+    uu = _ffi.Uniforms.from_buffer_copy(bytes(u))
+    for lim in [(0.01, 100.0, 0), (0.01, 100.0, 1), (0.01, 100.0, 3), (0.5, 3.0, 50), (1e-6, 1e6, 40),
+                (5.0, 1.0, 10)]:   # max_iter 0; tiny budgets; coarse; min_dist > max_dist
+        setup(res, cc=cc, words=w, u=uu, limits=lim, kernel=kernel)
+        assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_deep_stack_programs(res, oracle, kernel):
+    W, H = 48, 32
+    for scene in (scenes.right_deep(6), scenes.right_deep(32), scenes.g32_balanced()):
+        cc, w, u = oracle_case(oracle, scene, W, H, None)
+        lim = (0.01, 100.0, 64)
+        res.resize_command_buffer(4096)
+        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+        assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_program_leaving_two_values_returns_top(res, oracle, kernel):
+    # "S S" (no operator): the reference returns the top of stack (wgsl:202)
+    t = scenes._Tab()
+    a, b = t.sphere((0, 0, 0), 1.0), t.sphere((1.5, 0, 0), 0.7)
+    _, wa = oracle.serialize(t.nodes, a)
+    _, wb = oracle.serialize(t.nodes, b)
+    w = np.concatenate([wa, wb])
+    W, H = 40, 30
+    _, _, u = oracle_case(oracle, None, W, H, None)
+    lim = (0.01, 100.0, 64)
+    setup(res, cc=2, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    assert_same(res.draw(W, H), oracle.render(u, lim, 2, w, W, H))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_row_bands_and_tiling_invariance(res, oracle, kernel):
+    W, H = 96, 80
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    lim = (0.01, 100.0, 128)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    full = res.draw(W, H)
+    assert_same(full, oracle.render(u, lim, cc, w, W, H, threads=4))
+    for strip in (1, 7, 16, 33):
+        parts = [res.draw(W, H, r0, min(strip, H - r0)) for r0 in range(0, H, strip)]
+        assert np.concatenate(parts).tobytes() == full.tobytes()
+    band = res.draw(W, H, 13, 29)
+    assert_same(band, oracle.render(u, lim, cc, w, W, H, row0=13, rows=29))
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_batch_equals_single_draws(res, oracle, kernel):
+    W, H = 64, 36
+    cc, w = oracle.serialize(*scenes.g8())
+    lim = (0.01, 100.0, 64)
+    frames, refs = [], []
+    for f in range(5):
+        u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=[(1, 35.0 + 40.0 * f, -25.0)])
+        frames.append(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        refs.append(oracle.render(u, lim, cc, w, W, H, threads=4))
+    setup(res, cc=cc, words=w, u=frames[0], limits=lim, kernel=kernel)
+    out = res.draw_batch(frames, W, H)
+    for f in range(5):
+        assert_same(out[f], refs[f])
+
+
+def test_raw_write_buffer_path_and_stale_tail(res, oracle):
+    """prepare()'s literal call sequence (renderer.rs:213-239): raw byte writes; words beyond
+    the current program are stale and must be ignored (renderer.rs:230-239 never clears)."""
+    W, H = 48, 40
+    cc32, w32, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    cc1, w1 = oracle.serialize(*scenes.g1())
+    lim = (0.01, 100.0, 64)
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+    res.resize_command_buffer(1024)
+    res.write_buffer(_ffi.RM_BUF_LIMITS, 0, bytes(_ffi.Limits(*lim)))
+    res.write_buffer(_ffi.RM_BUF_UNIFORMS, 0, bytes(u))
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 0, np.uint32(cc32).tobytes())
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 4, w32.tobytes())
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc32, w32, W, H, threads=4))
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 0, np.uint32(cc1).tobytes())     # g32's tail stays behind
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 4, w1.tobytes())
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc1, w1, W, H, threads=4))
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 0, np.uint32(0).tobytes())       # csg_node == None
+    assert_same(res.draw(W, H), oracle.render(u, lim, 0, [], W, H, threads=4))
+
+
+def test_callback_prepare_paint_dropin(res, oracle):
+    """RayMarchingCallback::new(time, node, viewport, camera).prepare()/paint() end to end,
+    host mirror included, against the oracle's restatement of the same host code."""
+    W, H = 80, 60
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+    res.set_limits(renderer.RayMarchLimits())               # reference defaults {0.01, 100, 100}
+    ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
+    ctl.update(camera.Orbit([35.0, -25.0]))
+    cb = renderer.RayMarchingCallback.new(0.0, csg.scene("g8"), [float(W), float(H)], ctl.camera())
+    cb.prepare(res)
+    img = cb.paint(res)
+    cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
+    assert_same(img, oracle.render(u, (0.01, 100.0, 100), cc, w, W, H, threads=4))
+    none_cb = renderer.RayMarchingCallback.new(0.0, None, [float(W), float(H)], ctl.camera())
+    none_cb.prepare(res)
+    assert_same(none_cb.paint(res), oracle.render(u, (0.01, 100.0, 100), 0, [], W, H, threads=4))
+
+
+def test_abi_errors_on_device(res, oracle):
+    L = _ffi.hip_lib()
+    res.resize_command_buffer(1024)
+    with pytest.raises(_ffi.RmError) as e:
+        res.set_program(1, [0, 0, 0])
+    assert e.value.status == _ffi.RM_ERR_TRUNCATED
+    with pytest.raises(_ffi.RmError) as e:
+        res.set_program(1, [9])
+    assert e.value.status == _ffi.RM_ERR_OPCODE and "opcode" in str(e.value)
+    cc, w = oracle.serialize(*scenes.g64())
+    res.set_program(cc, w)                                     # 223 words fit the reference's 255
+    t = scenes._Tab()
+    prims = [t.box((i, 0, 0), (0.4, 0.4, 0.4)) for i in range(40)]
+    cc, w = oracle.serialize(t.nodes, scenes._fold_left(t, prims))   # 319 words > 255
+    with pytest.raises(_ffi.RmError) as e:
+        res.set_program(cc, w)
+    assert e.value.status == _ffi.RM_ERR_TOO_LARGE
+    res.resize_command_buffer(2048)
+    res.set_program(cc, w)
+    # raw garbage is caught at draw time, not executed
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 0, np.uint32(3).tobytes())
+    res.write_buffer(_ffi.RM_BUF_COMMANDS, 4, np.array([100, 100, 100], np.uint32).tobytes())
+    with pytest.raises(_ffi.RmError) as e:
+        res.draw(8, 8)
+    assert e.value.status == _ffi.RM_ERR_STACK_UNDERFLOW
+    with pytest.raises(_ffi.RmError) as e:
+        res.write_buffer(_ffi.RM_BUF_UNIFORMS, 140, b"\0" * 8)
+    assert e.value.status == _ffi.RM_ERR_TOO_LARGE
+    res.set_program(0, [])
+    for args in [(0, 8, 0, 8), (8, 8, 8, 1), (8, 8, 4, 5), (8, 8, 0, 0)]:
+        with pytest.raises(_ffi.RmError) as e:
+            res.draw(args[0], args[1], args[2], args[3])
+        assert e.value.status == _ffi.RM_ERR_RANGE
+    assert L.rm_draw(res._h, 8, 8, 0, 8, None, 0, None) == _ffi.RM_ERR_NULL
+
+
+@pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
+def test_metric_config_full_size_properties(res, oracle, kernel):
+    """BASELINE metric config: 1920x1080, G32, 256 steps.  Size-independent properties plus a
+    bit-exact comparison of sampled row bands against the oracle."""
+    W, H = 1920, 1080
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    lim = (0.01, 100.0, 256)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    full = res.draw(W, H)
+    assert np.isfinite(full).all()
+    assert np.array_equal(full[..., 3], np.ones((H, W), np.float32))          # alpha = 1 (wgsl:75)
+    assert full[..., :3].min() >= 0.0 and full[..., :3].max() <= 1.0
+    # tiling invariance: 8 interleaved 16-row strip sets (the multi-GPU partition) == full frame
+    strips = np.concatenate([res.draw(W, H, r0, min(16, H - r0)) for r0 in range(0, H, 16)])
+    assert hashlib.sha256(strips.tobytes()).digest() == hashlib.sha256(full.tobytes()).digest()
+    for r0, rows in [(0, 4), (403, 6), (536, 8), (777, 5), (1076, 4)]:
+        assert_same(full[r0:r0 + rows], oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=8))
+
+
+def test_metric_config_full_frame_vs_oracle(res, oracle):
+    """The whole 1920x1080 / G32 / 256-step frame, every pixel, default kernel vs oracle."""
+    W, H = 1920, 1080
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    lim = (0.01, 100.0, 256)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
+    img = res.draw(W, H)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=16)
+    assert_same(img, ref)
+
+
+def test_g64_512_steps_quarter_res(res, oracle):
+    """BASELINE config 4's scene/limits (G64, 512 steps) at 960x540."""
+    W, H = 960, 540
+    cc, w, u = oracle_case(oracle, scenes.g64(), W, H, None)
+    lim = (0.01, 100.0, 512)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=16))
+
+
+def test_device_output_and_stream(res, oracle):
+    torch = pytest.importorskip("torch")
+    W, H = 128, 72
+    cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
+    lim = (0.01, 100.0, 64)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
+    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.current_stream()
+    res.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    assert_same(out.cpu().numpy(), oracle.render(u, lim, cc, w, W, H, threads=4))
+    out.zero_()
+    res.draw_device(W, H, out.data_ptr())           # the context's own stream
+    res.sync()
+    assert_same(out.cpu().numpy(), oracle.render(u, lim, cc, w, W, H, threads=4))
+
+
+def test_write_bandwidth_calibration(res):
+    gbps = res.measure_write_bandwidth(1 << 28, 5)
+    assert 200.0 < gbps < 9000.0
