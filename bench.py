@@ -99,7 +99,8 @@ def main():
         return renderer.prepare_uniforms((float(W), float(H)), ctl.camera())
 
     out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream()          # the kernel, the events and the syncs all use THIS stream
+    torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
     def sync_all():

@@ -73,7 +73,7 @@ enum rm_status {
     RM_ERR_EMPTY_RESULT = -5,    /* program leaves nothing on the stack */
     RM_ERR_OPCODE = -6,          /* opcode the reference does not define (wgsl:223-225 would yield 0.0) */
     RM_ERR_TOO_LARGE = -7,       /* write past the end of a buffer / program larger than the buffer */
-    RM_ERR_RANGE = -8,           /* row band or image size out of range */
+    RM_ERR_RANGE = -8,           /* row band / image size out of range, or max_iter > 65536 */
     RM_ERR_DEVICE = -9,          /* a HIP call failed; see rm_last_error */
     RM_ERR_NO_DEVICE = -10,      /* no usable GPU */
     RM_ERR_ARG = -11             /* invalid enum / option value */
@@ -83,7 +83,8 @@ enum rm_status {
 enum rm_option {
     RM_OPT_KERNEL = 0,     /* which kernel rm_draw launches; see enum rm_kernel */
     RM_OPT_TIMING = 1,     /* 1: bracket every kernel launch with HIP events (rm_get_info RM_INFO_KERNEL_MS) */
-    RM_OPT_STRICT_CAP = 2  /* 1 (default): command buffer is exactly the reference's 1024 B unless resized */
+    RM_OPT_STRICT_CAP = 2, /* reserved */
+    RM_OPT_REFILL_MIN = 3  /* raypool kernels: parked lanes that trigger a refill, 1..64 (default 16) */
 };
 enum rm_kernel {
     RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */
@@ -133,8 +134,9 @@ int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_wo
 
 /* paint (renderer.rs:244-255) restricted to rows [row0,row0+rows) of a W x H target.
  * out_rgba receives rows*W*4 floats.  out_is_device = 0: host memory, filled on return.
- * out_is_device = 1: device memory on ctx's GPU; the launch is asynchronous on `stream`
- * (a hipStream_t, or NULL for the context's own stream; rm_sync waits for the latter). */
+ * out_is_device = 1: device memory on ctx's GPU; the launch is asynchronous on `stream`, a
+ * hipStream_t of the caller (NULL = HIP's null stream, as everywhere in HIP); the caller
+ * synchronises that stream, or calls rm_sync.  `stream` is ignored for host output. */
 int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, float* out_rgba,
             int out_is_device, void* stream);
 
@@ -143,6 +145,7 @@ int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, f
 int rm_draw_batch(rm_ctx* ctx, const rm_uniforms* frames, uint32_t n_frames, uint32_t W, uint32_t H,
                   float* out_rgba, int out_is_device, void* stream);
 
+/* Waits for all work on the context's GPU (hipDeviceSynchronize). */
 int rm_sync(rm_ctx* ctx);
 
 int rm_set_option(rm_ctx* ctx, int key, int64_t value);

@@ -30,13 +30,33 @@ RM_OK, RM_ERR_NULL, RM_ERR_TRUNCATED, RM_ERR_STACK_UNDERFLOW, RM_ERR_STACK_OVERF
 RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVICE = -5, -6, -7, -8, -9
 RM_ERR_NO_DEVICE, RM_ERR_ARG = -10, -11
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
-RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP = 0, 1, 2
+RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN = 0, 1, 2, 3
 RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0, 1, 2, 3
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT = 4, 5
 
 _hip = None
 _host = None
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  The torch wheel bundles its own libamdhip64.so (SONAME
+    libamdhip64.so.7, requested by libtorch_hip.so as plain "libamdhip64.so"); if librm_hip.so
+    pulled in /opt/rocm's copy first, a later `import torch` would load a SECOND runtime, which
+    then sees no GPU, and torch stream handles would be meaningless to us.  So when torch is
+    installed its copy is loaded first and librm_hip.so binds to it by SONAME.  Hosts without
+    torch (C++, Rust) simply use the system ROCm runtime.  RM_HIP_RUNTIME=system skips this."""
+    if os.environ.get("RM_HIP_RUNTIME", "") == "system":
+        return
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.submodule_search_locations:
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 def hip_lib():
@@ -46,6 +66,7 @@ def hip_lib():
         if not os.path.exists(HIP_SO):
             raise ImportError("%s is missing: run `python -m ray_marching_amd.build` (there is no CPU fallback)"
                               % HIP_SO)
+        _preload_hip_runtime()
         L = C.CDLL(HIP_SO)
         vp, u32, u64, i64 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int64
         L.rm_abi_version.restype = C.c_int

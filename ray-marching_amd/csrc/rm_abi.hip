@@ -23,6 +23,7 @@ namespace {
 constexpr uint64_t kRefCmdBufferBytes = 1024;  // renderer.rs:142-147
 constexpr uint64_t kMaxCmdBufferBytes = 65536;
 constexpr uint32_t kMaxDim = 1u << 16;
+constexpr uint32_t kMaxIter = 1u << 16;
 
 thread_local std::string g_create_error;
 
@@ -50,6 +51,7 @@ struct rm_ctx {
     size_t d_frames_cap = 0;
     // options / info
     int kernel = RM_KERNEL_DEFAULT;
+    uint32_t refill_min = 16;
     bool timing = false;
     double last_kernel_ms = 0.0;
     std::string err;
@@ -125,8 +127,20 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.frames = frames_dev;
     L.u = c->uniforms;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
-    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_PIXEL : c->kernel;
+    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_RAYPOOL : c->kernel;
     switch (kernel) {
+    case RM_KERNEL_RAYPOOL:
+    case RM_KERNEL_RAYPOOL_LDS: {
+        dim3 grid((W + 7u) / 8u, (rows + 7u) / 8u, n_frames);
+        const bool lds = kernel == RM_KERNEL_RAYPOOL_LDS;
+        size_t shmem = (1024u + 128u) * sizeof(float) + (size_t)L.spill_depth * 64u * sizeof(float) +
+                       (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u);
+        if (shmem > 160u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS", shmem);
+        if (lds)
+            hipLaunchKernelGGL((rmk::rm_render_raypool<rmk::ProgLds, true>), grid, dim3(64), shmem, s, L, c->refill_min);
+        else
+            hipLaunchKernelGGL((rmk::rm_render_raypool<rmk::ProgSmem, false>), grid, dim3(64), shmem, s, L, c->refill_min);
+    } break;
     case RM_KERNEL_PIXEL: {
         dim3 grid((W + 15u) / 16u, (rows + 15u) / 16u, n_frames);
         size_t shmem = (size_t)L.n_rec * sizeof(RmRecord) + (size_t)L.spill_depth * 256u * sizeof(float);
@@ -150,6 +164,14 @@ int check_dims(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows) 
     if (W == 0 || H == 0 || W > kMaxDim || H > kMaxDim) return fail(c, RM_ERR_RANGE, "image size %ux%u out of range", W, H);
     if (rows == 0 || row0 >= H || rows > H - row0)
         return fail(c, RM_ERR_RANGE, "row band [%u,+%u) outside image height %u", row0, rows, H);
+    return RM_OK;
+}
+
+// A draw with an astronomically large max_iter would never finish (an empty scene marches all
+// max_iter steps, wgsl:189-191 + :109); refuse it instead of hanging the GPU.
+int check_limits(rm_ctx* c) {
+    if (c->limits.max_iter > kMaxIter)
+        return fail(c, RM_ERR_RANGE, "max_iter %u exceeds the supported maximum %u", c->limits.max_iter, kMaxIter);
     return RM_OK;
 }
 
@@ -300,9 +322,11 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     rc = ensure_program(c);
     if (rc != RM_OK) return rc;
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    rc = check_limits(c);
+    if (rc != RM_OK) return rc;
     const size_t bytes = (size_t)rows * W * 16u;
-    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, s);
+    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, static_cast<hipStream_t>(stream));
+    hipStream_t s = c->stream;
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
     rc = launch(c, nullptr, 1, W, H, row0, rows, c->d_out, s);
@@ -322,7 +346,9 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     HIP_TRY(c, hipSetDevice(c->device));
     rc = ensure_program(c);
     if (rc != RM_OK) return rc;
-    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    rc = check_limits(c);
+    if (rc != RM_OK) return rc;
+    hipStream_t s = out_is_device ? static_cast<hipStream_t>(stream) : c->stream;
     if (n_frames > c->d_frames_cap) {
         if (c->d_frames) (void)hipFree(c->d_frames);
         c->d_frames = nullptr;
@@ -345,7 +371,7 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
 RM_EXPORT int rm_sync(rm_ctx* c) {
     if (!c) return RM_ERR_NULL;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipDeviceSynchronize());
     return RM_OK;
 }
 
@@ -358,6 +384,10 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
         return RM_OK;
     case RM_OPT_TIMING: c->timing = value != 0; return RM_OK;
     case RM_OPT_STRICT_CAP: return RM_OK;
+    case RM_OPT_REFILL_MIN:
+        if (value < 1 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [1,64]", (long long)value);
+        c->refill_min = (uint32_t)value;
+        return RM_OK;
     default: return fail(c, RM_ERR_ARG, "unknown option %d", key);
     }
 }

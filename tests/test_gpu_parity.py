@@ -265,15 +265,22 @@ def test_device_output_and_stream(res, oracle):
     cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
     lim = (0.01, 100.0, 64)
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
-    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda:0")
-    s = torch.cuda.current_stream()
-    res.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+    out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    s = torch.cuda.Stream()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(s):
+        e0.record(s)
+        res.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)
+        e1.record(s)
     s.synchronize()
-    assert_same(out.cpu().numpy(), oracle.render(u, lim, cc, w, W, H, threads=4))
+    assert e0.elapsed_time(e1) > 0.0                # the events bracket a real kernel on that stream
+    assert_same(out.cpu().numpy(), ref)
     out.zero_()
-    res.draw_device(W, H, out.data_ptr())           # the context's own stream
+    torch.cuda.synchronize()
+    res.draw_device(W, H, out.data_ptr())           # stream NULL = HIP's null stream
     res.sync()
-    assert_same(out.cpu().numpy(), oracle.render(u, lim, cc, w, W, H, threads=4))
+    assert_same(out.cpu().numpy(), ref)
 
 
 def test_write_bandwidth_calibration(res):
