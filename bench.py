@@ -33,10 +33,27 @@ def parse():
     p.add_argument("--scene", default="g32")
     p.add_argument("--max-iter", type=int, default=256)
     p.add_argument("--kernel", type=int, default=0, help="rm_kernel enum (0 = default tuned kernel)")
+    p.add_argument("--refill-min", type=int, default=0, help="raypool refill threshold (0 = library default)")
+    p.add_argument("--waves-per-tile", type=int, default=0, help="v3 kernels: 1/2/4/8 waves share a tile (0 = default)")
+    p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
+    p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
     p.add_argument("--camera", choices=["still", "orbit"], default="still")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders W/div x H/div")
     return p.parse_args()
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def cpu_baseline(args, scene_words, cam_events):
@@ -46,7 +63,7 @@ def cpu_baseline(args, scene_words, cam_events):
     cbind.build()
     cc, words = scene_words
     W, H = args.width // args.cpu_sample_div, args.height // args.cpu_sample_div
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     u, *_ = cbind.orbit_uniforms((float(W), float(H)), events=cam_events)
     lim = (0.01, 100.0, args.max_iter)
     cbind.render(u, lim, cc, words, 64, 36, threads=cores)     # warm the threads / caches
@@ -81,6 +98,14 @@ def main():
     W, H = args.width, args.height
     res = renderer.RayMarchingResources(local_rank)
     res.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
+    if args.refill_min:
+        res.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
+    if args.waves_per_tile:
+        res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, args.waves_per_tile)
+    if args.no_cull:
+        res.set_option(_ffi.RM_OPT_CULL, 0)
+    if args.no_balance:
+        res.set_option(_ffi.RM_OPT_BALANCE, 0)
     res.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
     node = csg.scene(args.scene)
     cc, words = csg.serialize(node)

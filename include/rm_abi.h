@@ -84,13 +84,23 @@ enum rm_option {
     RM_OPT_KERNEL = 0,     /* which kernel rm_draw launches; see enum rm_kernel */
     RM_OPT_TIMING = 1,     /* 1: bracket every kernel launch with HIP events (rm_get_info RM_INFO_KERNEL_MS) */
     RM_OPT_STRICT_CAP = 2, /* reserved */
-    RM_OPT_REFILL_MIN = 3  /* raypool kernels: parked lanes that trigger a refill, 1..64 (default 16) */
+    RM_OPT_REFILL_MIN = 3, /* raypool kernels: parked lanes that trigger a refill, 1..64 (default 8) */
+    RM_OPT_CULL = 4,       /* v3 kernels: 1 (default) = shade rays that provably miss the scene without marching */
+    RM_OPT_BALANCE = 5,    /* v3 kernels: 1 (default) = cost pre-pass + heaviest-tile-first dispatch order */
+    RM_OPT_WAVES_PER_TILE = 7, /* v3 kernels: waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
+    RM_OPT_WAVE_STATS = 6  /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
 };
 enum rm_kernel {
     RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */
     RM_KERNEL_PIXEL = 1,     /* v1: one thread per pixel, program staged in LDS, lock-step AA loop */
     RM_KERNEL_RAYPOOL = 2,   /* v2: per-wave ray pool, ballot-driven refill, program through the scalar cache */
-    RM_KERNEL_RAYPOOL_LDS = 3 /* v2 with the program read from LDS */
+    RM_KERNEL_RAYPOOL_LDS = 3, /* v2 with the program read from LDS */
+    /* v3: ray pool with R rays in flight per lane, lean interpreter (scalar-cache / LDS program) */
+    RM_KERNEL_MULTI1 = 4, RM_KERNEL_MULTI1_LDS = 5,
+    RM_KERNEL_MULTI2 = 6, RM_KERNEL_MULTI2_LDS = 7,
+    RM_KERNEL_MULTI4 = 8, RM_KERNEL_MULTI4_LDS = 9,
+    /* v4: ray pool with LDS ready/shade queues: ray generation, culling and shading run 64 rays at a time */
+    RM_KERNEL_QUEUE = 10, RM_KERNEL_QUEUE_LDS = 11
 };
 enum rm_info {
     RM_INFO_KERNEL_MS = 0,       /* duration of the last timed kernel launch, milliseconds */
@@ -154,6 +164,11 @@ int rm_get_info(rm_ctx* ctx, int key, double* out);
 /* Stream-write calibration: a fill kernel writes `bytes` of device memory `iters` times
  * with 16 B/lane stores; reports the achieved GB/s (the measured HBM-write ceiling). */
 int rm_measure_write_bandwidth(rm_ctx* ctx, uint64_t bytes, int iters, double* out_gbps);
+
+/* Diagnostics: per-wave records of the last draw made with RM_OPT_WAVE_STATS = 1, four u64 per
+ * wave in dispatch order: [0] start, [1] end (100 MHz s_memrealtime ticks), [2] tile id << 32 |
+ * map_scene iterations, [3] refills << 32 | sum over iterations of live lanes. */
+int rm_read_wave_stats(rm_ctx* ctx, void* dst, uint64_t cap_bytes, uint64_t* out_bytes);
 
 /* Message for the last error on this context (ctx may be NULL: last rm_create error). */
 const char* rm_last_error(rm_ctx* ctx);

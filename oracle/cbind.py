@@ -165,7 +165,7 @@ def orbit_uniforms(viewport, target=(0, 0, 0), radius=5.0, events=()):
     """OrbitCameraController::new(target, radius) + events -> prepared Uniforms (renderer.rs:205-222)."""
     L = lib()
     orb = Orbit()
-    t = np.asarray(target, dtype=np.float32)
+    t = np.ascontiguousarray(np.asarray(target, dtype=np.float32))
     L.rmo_orbit_new(C.byref(orb), _f32p(t), radius)
     for ev, dx, dy in events:
         L.rmo_orbit_update(C.byref(orb), ev, dx, dy)

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-HIP_SO = os.path.join(PKG, "librm_hip.so")
+HIP_SO = os.environ.get("RM_HIP_SO") or os.path.join(PKG, "librm_hip.so")   # RM_HIP_SO: A/B builds
 HOST_SO = os.path.join(PKG, "librm_host.so")
 
 
@@ -30,8 +30,12 @@ RM_OK, RM_ERR_NULL, RM_ERR_TRUNCATED, RM_ERR_STACK_UNDERFLOW, RM_ERR_STACK_OVERF
 RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVICE = -5, -6, -7, -8, -9
 RM_ERR_NO_DEVICE, RM_ERR_ARG = -10, -11
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
-RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN = 0, 1, 2, 3
+RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
+RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE = 5, 6, 7
 RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0, 1, 2, 3
+RM_KERNEL_MULTI1, RM_KERNEL_MULTI1_LDS, RM_KERNEL_MULTI2, RM_KERNEL_MULTI2_LDS = 4, 5, 6, 7
+RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
+RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT = 4, 5
 
@@ -88,6 +92,8 @@ def hip_lib():
         L.rm_set_option.argtypes = [vp, C.c_int, i64]
         L.rm_get_info.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
         L.rm_measure_write_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
+        L.rm_read_wave_stats.argtypes = [vp, vp, u64, C.POINTER(u64)]
+        L.rm_read_wave_stats.restype = C.c_int
         L.rm_last_error.argtypes = [vp]
         L.rm_last_error.restype = C.c_char_p
         L.rm_status_string.argtypes = [C.c_int]

@@ -20,7 +20,9 @@ HIP_SO = os.path.join(PKG, "librm_hip.so")
 HOST_SO = os.path.join(PKG, "librm_host.so")
 
 # -ffp-contract=off: the arithmetic contract forbids fused multiply-add.
+# -fno-slp-vectorize: packed-f32 (v_pk_*) code plus its register shuffles measured 3 % slower.
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+             "-fno-slp-vectorize",
              "-fPIC", "-shared", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 HOST_FLAGS = ["-O2", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
               "-fvisibility=hidden", "-Wall", "-Wextra"]

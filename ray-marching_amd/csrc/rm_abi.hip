@@ -15,6 +15,8 @@
 #include "rm_decode.h"
 #include "rm_device.h"
 #include "rm_kernels.h"
+#include "rm_kernel_multi.h"
+#include "rm_kernel_queue.h"
 
 #define RM_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -51,7 +53,16 @@ struct rm_ctx {
     size_t d_frames_cap = 0;
     // options / info
     int kernel = RM_KERNEL_DEFAULT;
-    uint32_t refill_min = 16;
+    uint32_t refill_min = 8;
+    bool cull = true;
+    bool balance = true;
+    int waves_per_tile = 4;
+    bool wave_stats = false;
+    unsigned long long* d_stats = nullptr;
+    size_t d_stats_bytes = 0, stats_valid_bytes = 0;
+    uint32_t* d_cost = nullptr;   // per-tile cost estimates / dispatch order of the balance pre-pass
+    uint32_t* d_order = nullptr;
+    size_t d_tiles_cap = 0;
     bool timing = false;
     double last_kernel_ms = 0.0;
     std::string err;
@@ -113,21 +124,111 @@ int ensure_program(rm_ctx* c) {
     return RM_OK;
 }
 
+int finish_launch(rm_ctx* c, hipStream_t s);
+
+template <int R, int WPT>
+int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
+    using G = rmk::TileGeom<R>;
+    RmLaunch L = L_in;
+    // Miss-ray culling: one table entry per command, kept in LDS; very long programs go without.
+    // An empty scene evaluates to max_dist everywhere (wgsl:189-191): no ray can hit unless
+    // max_dist < min_dist, so (only) then the all-miss shortcut must stay off.
+    bool cull = c->cull && L.n_rec <= 256u;
+    if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;
+    L.n_cull = cull ? L.n_rec : 0u;
+    L.flags = cull ? 1u : 0u;
+    const uint32_t n_tiles = ((L.W + G::TW - 1u) / G::TW) * ((L.rows + G::TH - 1u) / G::TH);
+    dim3 grid(n_tiles, 1, n_frames);
+    size_t shmem = (size_t)18u * G::PIX * sizeof(float) + (size_t)L.spill_depth * R * 64u * WPT * sizeof(float) +
+                   (size_t)L.n_cull * 16u + (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
+    if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
+    // Heaviest-tile-first dispatch order (see rm_tile_cost); pointless when nothing can be culled
+    // cheaply estimated (culling off) or when the frame has fewer tiles than the chip has wave slots.
+    if (c->balance && cull && L.n_rec != 0u && L.max_iter != 0u) {
+        const size_t need = (size_t)n_tiles * n_frames;
+        if (need > c->d_tiles_cap) {
+            if (c->d_cost) (void)hipFree(c->d_cost);
+            if (c->d_order) (void)hipFree(c->d_order);
+            c->d_cost = c->d_order = nullptr;
+            c->d_tiles_cap = 0;
+            HIP_TRY(c, hipMalloc(&c->d_cost, need * sizeof(uint32_t)));
+            HIP_TRY(c, hipMalloc(&c->d_order, need * sizeof(uint32_t)));
+            c->d_tiles_cap = need;
+        }
+        hipLaunchKernelGGL((rmk::rm_tile_cost<R>), grid, dim3(64), (size_t)L.n_cull * 16u, s, L, c->d_cost);
+        hipLaunchKernelGGL(rmk::rm_tile_sort, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, n_tiles);
+        L.order = c->d_order;
+    }
+    if (c->wave_stats) {
+        const size_t need = (size_t)n_tiles * n_frames * WPT * 4u * sizeof(unsigned long long);
+        if (need > c->d_stats_bytes) {
+            if (c->d_stats) (void)hipFree(c->d_stats);
+            c->d_stats = nullptr;
+            c->d_stats_bytes = 0;
+            HIP_TRY(c, hipMalloc(&c->d_stats, need));
+            c->d_stats_bytes = need;
+        }
+        c->stats_valid_bytes = need;
+        L.stats = c->d_stats;
+    }
+    if (lds)
+        hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgLds, true, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
+    else
+        hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgSmem, false, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
+    return finish_launch(c, s);
+}
+
+template <int R>
+int launch_multi(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
+    // Deep value stacks spill [depth][R][64] floats per wave: use fewer waves per tile when the
+    // requested number would not fit the LDS budget of one workgroup.
+    int wpt = c->waves_per_tile;
+    const size_t fixed = (size_t)18u * rmk::TileGeom<R>::PIX * 4u + (size_t)L.n_rec * (16u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
+    while (wpt > 1 && fixed + (size_t)L.spill_depth * R * 64u * 4u * wpt > 48u * 1024u) wpt /= 2;
+    switch (wpt) {
+    case 1: return launch_multi_w<R, 1>(c, L, lds, n_frames, s);
+    case 2: return launch_multi_w<R, 2>(c, L, lds, n_frames, s);
+    case 8: return launch_multi_w<R, 8>(c, L, lds, n_frames, s);
+    default: return launch_multi_w<R, 4>(c, L, lds, n_frames, s);
+    }
+}
+
+int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
+    RmLaunch L = L_in;
+    bool cull = c->cull && L.n_rec <= 256u;
+    if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi
+    L.n_cull = cull ? L.n_rec : 0u;
+    L.flags = cull ? 1u : 0u;
+    dim3 grid((L.W + 7u) / 8u, (L.rows + 7u) / 8u, n_frames);
+    size_t shmem = (size_t)(1024u + 4u * rmk::QCAP + 7u * rmk::QCAP) * 4u + (size_t)L.spill_depth * 64u * 4u +
+                   (size_t)L.n_cull * 16u + (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u);
+    if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per wave", shmem);
+    if (lds)
+        hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgLds, true>), grid, dim3(64), shmem, s, L);
+    else
+        hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgSmem, false>), grid, dim3(64), shmem, s, L);
+    return finish_launch(c, s);
+}
+
 int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t row0,
            uint32_t rows, float* d_out, hipStream_t s) {
     RmLaunch L;
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
     L.spill_depth = c->decoded.spill_depth;
+    L.n_cull = 0;
+    L.flags = 0;
     L.min_dist = c->limits.min_dist;
     L.max_dist = c->limits.max_dist;
     L.max_iter = c->limits.max_iter;
     L.W = W; L.H = H; L.row0 = row0; L.rows = rows;
     L.out = d_out;
     L.frames = frames_dev;
+    L.order = nullptr;
+    L.stats = nullptr;
     L.u = c->uniforms;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
-    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_RAYPOOL : c->kernel;
+    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_MULTI1_LDS : c->kernel;
     switch (kernel) {
     case RM_KERNEL_RAYPOOL:
     case RM_KERNEL_RAYPOOL_LDS: {
@@ -146,9 +247,17 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
         size_t shmem = (size_t)L.n_rec * sizeof(RmRecord) + (size_t)L.spill_depth * 256u * sizeof(float);
         hipLaunchKernelGGL(rmk::rm_render_pixel, grid, dim3(256), shmem, s, L);
     } break;
+    case RM_KERNEL_QUEUE: case RM_KERNEL_QUEUE_LDS: return launch_queue(c, L, kernel == RM_KERNEL_QUEUE_LDS, n_frames, s);
+    case RM_KERNEL_MULTI1: case RM_KERNEL_MULTI1_LDS: return launch_multi<1>(c, L, kernel == RM_KERNEL_MULTI1_LDS, n_frames, s);
+    case RM_KERNEL_MULTI2: case RM_KERNEL_MULTI2_LDS: return launch_multi<2>(c, L, kernel == RM_KERNEL_MULTI2_LDS, n_frames, s);
+    case RM_KERNEL_MULTI4: case RM_KERNEL_MULTI4_LDS: return launch_multi<4>(c, L, kernel == RM_KERNEL_MULTI4_LDS, n_frames, s);
     default:
         return fail(c, RM_ERR_ARG, "kernel variant %d is not available", kernel);
     }
+    return finish_launch(c, s);
+}
+
+int finish_launch(rm_ctx* c, hipStream_t s) {
     HIP_TRY(c, hipGetLastError());
     if (c->timing) {
         HIP_TRY(c, hipEventRecord(c->ev1, s));
@@ -230,6 +339,9 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_prog) (void)hipFree(c->d_prog);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_frames) (void)hipFree(c->d_frames);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_cost) (void)hipFree(c->d_cost);
+    if (c->d_order) (void)hipFree(c->d_order);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -379,11 +491,18 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     if (!c) return RM_ERR_NULL;
     switch (key) {
     case RM_OPT_KERNEL:
-        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_RAYPOOL_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_QUEUE_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = (int)value;
         return RM_OK;
     case RM_OPT_TIMING: c->timing = value != 0; return RM_OK;
     case RM_OPT_STRICT_CAP: return RM_OK;
+    case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
+    case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
+    case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
+    case RM_OPT_WAVES_PER_TILE:
+        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RM_ERR_ARG, "waves_per_tile must be 1, 2, 4 or 8");
+        c->waves_per_tile = (int)value;
+        return RM_OK;
     case RM_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [1,64]", (long long)value);
         c->refill_min = (uint32_t)value;
@@ -410,6 +529,17 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     }
     default: return fail(c, RM_ERR_ARG, "unknown info key %d", key);
     }
+}
+
+RM_EXPORT int rm_read_wave_stats(rm_ctx* c, void* dst, uint64_t cap_bytes, uint64_t* out_bytes) {
+    if (!c) return RM_ERR_NULL;
+    if (!dst || !out_bytes) return fail(c, RM_ERR_NULL, "rm_read_wave_stats: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    const uint64_t n = c->stats_valid_bytes < cap_bytes ? c->stats_valid_bytes : cap_bytes;
+    if (n) HIP_TRY(c, hipMemcpy(dst, c->d_stats, n, hipMemcpyDeviceToHost));
+    *out_bytes = n;
+    return RM_OK;
 }
 
 RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, double* out_gbps) {

@@ -35,10 +35,14 @@ struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
     uint32_t n_rec;            // == cmd_count of the reference program
     uint32_t spill_depth;      // LDS value-stack slots per lane this program needs
+    uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
+    uint32_t flags;            // bit 0: miss-ray culling enabled
     float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
     uint32_t max_iter;
     uint32_t W, H, row0, rows;
     float* out;                // rows*W*4 floats per frame
+    unsigned long long* stats; // diagnostics (RM_OPT_WAVE_STATS): 4 x u64 per wave, or nullptr
+    const uint32_t* order;     // nullptr: tiles in raster order; else dispatch slot -> tile id, per frame
     const rm_uniforms* frames; // nullptr: use `u`; else frames[blockIdx.z]
     rm_uniforms u;
 };

@@ -113,6 +113,13 @@ class RayMarchingResources:
         self._check(self._L.rm_get_info(self._h, key, C.byref(v)))
         return v.value
 
+    def wave_stats(self, max_waves=1 << 20):
+        """Diagnostics: (n_waves, 4) uint64 array recorded by the last draw with RM_OPT_WAVE_STATS."""
+        buf = np.zeros((max_waves, 4), dtype=np.uint64)
+        n = C.c_uint64(0)
+        self._check(self._L.rm_read_wave_stats(self._h, buf.ctypes.data_as(C.c_void_p), buf.nbytes, C.byref(n)))
+        return buf[: n.value // 32]
+
     def measure_write_bandwidth(self, nbytes=1 << 30, iters=10):
         v = C.c_double()
         self._check(self._L.rm_measure_write_bandwidth(self._h, nbytes, iters, C.byref(v)))

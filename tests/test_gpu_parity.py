@@ -15,8 +15,11 @@ from ray_marching_amd import _ffi, camera, csg, renderer
 pytestmark = pytest.mark.gpu
 
 TOLERANCE = 1e-4      # contract (BASELINE.json north_star); asserted bit-exact below
-KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_LDS]
-KERNEL_IDS = ["pixel", "raypool", "raypool_lds"]
+KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_LDS,
+           _ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_MULTI2_LDS,
+           _ffi.RM_KERNEL_MULTI4, _ffi.RM_KERNEL_MULTI4_LDS, _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS]
+KERNEL_IDS = ["pixel", "raypool", "raypool_lds", "multi1", "multi1_lds", "multi2", "multi2_lds", "multi4",
+              "multi4_lds", "queue", "queue_lds"]
 IDX = G.index()
 
 
@@ -143,6 +146,68 @@ def test_batch_equals_single_draws(res, oracle, kernel):
     out = res.draw_batch(frames, W, H)
     for f in range(5):
         assert_same(out[f], refs[f])
+
+
+CULL_CAMERAS = {
+    "still": dict(events=scenes.STILL_CAMERA_EVENTS),
+    "inside_solid": dict(events=[(2, -95.0, 0.0)]),
+    "far": dict(events=[(1, 35.0, -25.0), (2, 300.0, 0.0)]),
+    "top_down": dict(events=[(1, 10.0, -150.0)]),
+    "from_below": dict(events=[(1, -80.0, 150.0)]),
+    "panned_off_axis": dict(events=[(1, 35.0, -25.0), (0, 180.0, 90.0)]),
+    "far_from_origin": dict(target=(1000.0, -2000.0, 500.0), events=[(1, 35.0, -25.0)]),
+    "grazing_zoom": dict(events=[(1, 3.0, -6.0), (2, -60.0, 0.0), (0, 115.0, 12.0)]),
+}
+
+
+@pytest.mark.parametrize("cam", sorted(CULL_CAMERAS))
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2,
+                                    _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS],
+                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds"])
+def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
+    """The bounding-cone shortcut must never change a pixel: culling on == culling off == oracle,
+    for cameras outside, inside, far from and grazing the scene, and for several min_dist."""
+    W, H = 72, 48
+    spec = CULL_CAMERAS[cam]
+    for scene_name in ("g8", "g32"):
+        nodes, root = scenes.SCENES[scene_name]()
+        if "target" in spec:   # move the whole scene along with the camera target
+            nodes = [(k, ([p[0] + spec["target"][0], p[1] + spec["target"][1], p[2] + spec["target"][2]] + list(p[3:]))
+                      if k in (0, 1) else p, l, r) for (k, p, l, r) in nodes]
+        cc, w = oracle.serialize(nodes, root)
+        u, *_ = oracle.orbit_uniforms((float(W), float(H)), target=spec.get("target", (0, 0, 0)), events=spec["events"])
+        uu = _ffi.Uniforms.from_buffer_copy(bytes(u))
+        for lim in [(0.01, 100.0, 96), (0.6, 100.0, 40), (2.5, 50.0, 20)]:
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=uu, limits=lim, kernel=kernel)
+            res.set_option(_ffi.RM_OPT_CULL, 0)
+            off = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_CULL, 1)
+            res.set_option(_ffi.RM_OPT_BALANCE, 0)
+            on = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_BALANCE, 1)      # heaviest-tile-first order: same pixels
+            bal = res.draw(W, H)
+            assert_same(off, ref)
+            assert_same(on, ref)
+            assert_same(bal, ref)
+
+
+def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
+    W, H = 56, 40
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    uu = _ffi.Uniforms.from_buffer_copy(bytes(u))
+    t = scenes._Tab()
+    weird = [t.sphere((0, 0, 0), -0.5), t.box((1.2, 0, 0), (0.0, 0.0, 0.0)), t.box((-1.2, 0, 0), (-0.3, 0.4, 0.2)),
+             t.sphere((0, 1.0, 0), 0.0), t.sphere((0.3, -0.4, 0.2), 1e-3), t.box((0, 0, -1), (1e3, 1e-3, 1e-3))]
+    cc, w = oracle.serialize(t.nodes, scenes._fold_left(t, weird))
+    res.set_option(_ffi.RM_OPT_CULL, 1)
+    for lim in [(0.01, 100.0, 64), (0.7, 100.0, 64)]:
+        setup(res, cc=cc, words=w, u=uu, limits=lim)
+        assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+    # empty scene: map_scene == max_dist everywhere; with max_dist < min_dist every ray HITS at step 0
+    for lim in [(0.01, 100.0, 12), (5.0, 1.0, 12), (5.0, 5.0, 3)]:
+        setup(res, cc=0, words=[], u=uu, limits=lim)
+        assert_same(res.draw(W, H), oracle.render(u, lim, 0, [], W, H, threads=4))
 
 
 def test_raw_write_buffer_path_and_stale_tail(res, oracle):
