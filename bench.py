@@ -38,8 +38,12 @@ def parse():
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
     p.add_argument("--camera", choices=["still", "orbit"], default="still")
+    p.add_argument("--mode", choices=["frames", "tile"], default="frames",
+                   help="frames: every rank renders whole frames (weak scaling, default); tile: ONE frame per step "
+                        "is tiled over the ranks in interleaved 16-row strips (strong scaling, north-star layout)")
+    p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-sample-div", type=int, default=2, help="CPU baseline renders W/div x H/div")
+    p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
     return p.parse_args()
 
 
@@ -123,7 +127,11 @@ def main():
             ctl.set_angles(2.0 * 3.141592653589793 * f / 1024.0, -0.25, 5.0)
         return renderer.prepare_uniforms((float(W), float(H)), ctl.camera())
 
-    out = torch.empty((H, W, 4), dtype=torch.float32, device="cuda")
+    from ray_marching_amd import shard
+    tile = args.mode == "tile"
+    my_rows = shard.strip_row_count(H, shard.DEFAULT_STRIP_ROWS, rank, world) if tile else H
+    out = torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda")
+    gloo = dist.new_group(backend="gloo") if (tile and args.gather and world > 1) else None
     stream = torch.cuda.Stream()          # the kernel, the events and the syncs all use THIS stream
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
@@ -133,18 +141,27 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def draw():
+        if tile:
+            res.draw_strips_device(W, H, shard.DEFAULT_STRIP_ROWS, rank, world, out.data_ptr(), stream=sptr)
+            if args.gather:      # final host-side gather (D2H + gloo), never RCCL
+                stream.synchronize()
+                shard.gather_image(out[:my_rows].cpu().numpy(), W, H, rank, world, group=gloo)
+        else:
+            res.draw_device(W, H, out.data_ptr(), stream=sptr)
+
     total = args.warmup + args.steps
     unis = [uniforms_for(s) for s in range(total)]
     for s in range(args.warmup):
         res.set_uniforms(unis[s])
-        res.draw_device(W, H, out.data_ptr(), stream=sptr)
+        draw()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
         res.set_uniforms(unis[args.warmup + k])            # prepare(): uniform write
         ev[k][0].record(stream)
-        res.draw_device(W, H, out.data_ptr(), stream=sptr)  # paint(): the kernel, on this stream
+        draw()                                              # paint(): the kernel, on this stream
         ev[k][1].record(stream)
     torch.cuda.synchronize()
     if world > 1:
@@ -159,9 +176,9 @@ def main():
 
     checksum = float(out[..., :3].double().sum().item())    # touches the result: nothing was skipped
     if rank == 0:
-        pixels = W * H * args.steps * world
+        pixels = W * H * args.steps * (1 if tile else world)
         value = pixels / elapsed / 1e6
-        ach = BYTES_PER_PIXEL * W * H / (kernel_ms * 1e-3) / 1e9
+        ach = BYTES_PER_PIXEL * W * (my_rows if tile else H) / (kernel_ms * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -173,12 +190,14 @@ def main():
         line = {
             "metric": "Mpixels/s at 1920x1080, 256-step march, 32-node SDF",
             "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tile else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d, %s (%d commands / %d words), %d max steps, 16 rays/px, RGBA32F out"
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
                        "camera": args.camera, "kernel": args.kernel,
-                       "sharding": "frames over ranks, no collective" if world > 1 else "single GPU"},
+                       "sharding": ("one frame tiled over ranks in interleaved 16-row strips%s, no collective"
+                                    % (" + host gather" if args.gather else "")) if tile
+                       else ("frames over ranks, no collective" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel_ms": kernel_ms,

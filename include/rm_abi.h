@@ -150,6 +150,14 @@ int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_wo
 int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, float* out_rgba,
             int out_is_device, void* stream);
 
+/* One GPU's share of an image tiled over `stride` GPUs (north-star: "the image tiles across the
+ * GPUs of one node with a final host-side gather"): renders the strips first, first+stride,
+ * first+2*stride, ... of strip_rows rows each (strip_rows a multiple of 16) in ONE launch.
+ * out_rgba receives them back to back; *out_rows = number of rows written (0 if this GPU has no
+ * strip).  Interleaving balances the load: the costly part of a frame is usually its centre. */
+int rm_draw_strips(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,
+                   float* out_rgba, int out_is_device, void* stream, uint32_t* out_rows);
+
 /* n_frames draws that differ only in their uniforms (camera-orbit batch); frame f is
  * written at out_rgba + f*W*H*4. */
 int rm_draw_batch(rm_ctx* ctx, const rm_uniforms* frames, uint32_t n_frames, uint32_t W, uint32_t H,

@@ -87,6 +87,8 @@ def hip_lib():
         L.rm_validate_program.argtypes = [u32, C.POINTER(u32), u32, C.POINTER(u32)]
         L.rm_validate_program.restype = C.c_int
         L.rm_draw.argtypes = [vp, u32, u32, u32, u32, vp, C.c_int, vp]
+        L.rm_draw_strips.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int, vp, C.POINTER(u32)]
+        L.rm_draw_strips.restype = C.c_int
         L.rm_draw_batch.argtypes = [vp, C.POINTER(Uniforms), u32, u32, u32, vp, C.c_int, vp]
         L.rm_sync.argtypes = [vp]
         L.rm_set_option.argtypes = [vp, C.c_int, i64]

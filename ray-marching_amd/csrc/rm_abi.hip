@@ -210,9 +210,12 @@ int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, h
     return finish_launch(c, s);
 }
 
+struct StripSpec { uint32_t rows = 0, first = 0, stride = 0; };
+
 int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t W, uint32_t H, uint32_t row0,
-           uint32_t rows, float* d_out, hipStream_t s) {
+           uint32_t rows, float* d_out, hipStream_t s, StripSpec strips = StripSpec()) {
     RmLaunch L;
+    L.strip_rows = strips.rows; L.strip_first = strips.first; L.strip_stride = strips.stride;
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
     L.spill_depth = c->decoded.spill_depth;
@@ -445,6 +448,48 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_rgba, c->d_out, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+// Output rows of the strips first, first+stride, ... (strip_rows rows each) of an H-row image.
+static uint32_t strip_row_count(uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride) {
+    const uint32_t n_strips = (H + strip_rows - 1u) / strip_rows;
+    uint32_t rows = 0;
+    for (uint32_t sidx = first; sidx < n_strips; sidx += stride) {
+        const uint32_t r0 = sidx * strip_rows;
+        rows += H - r0 < strip_rows ? H - r0 : strip_rows;
+    }
+    return rows;
+}
+
+RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,
+                             float* out_rgba, int out_is_device, void* stream, uint32_t* out_rows) {
+    if (!c) return RM_ERR_NULL;
+    if (!out_rows) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rows is NULL");
+    int rc = check_dims(c, W, H, 0, H);
+    if (rc != RM_OK) return rc;
+    if (strip_rows == 0u || (strip_rows % 16u) != 0u || stride == 0u || first >= stride)
+        return fail(c, RM_ERR_ARG, "rm_draw_strips: strip_rows %u must be a positive multiple of 16, first %u < stride %u",
+                    strip_rows, first, stride);
+    const uint32_t rows = strip_row_count(H, strip_rows, first, stride);
+    *out_rows = rows;
+    if (rows == 0u) return RM_OK;  // more ranks than strips: nothing to do for this one
+    if (!out_rgba) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rgba is NULL");
+    HIP_TRY(c, hipSetDevice(c->device));
+    rc = ensure_program(c);
+    if (rc != RM_OK) return rc;
+    rc = check_limits(c);
+    if (rc != RM_OK) return rc;
+    StripSpec sp;
+    sp.rows = strip_rows; sp.first = first; sp.stride = stride;
+    const size_t bytes = (size_t)rows * W * 16u;
+    if (out_is_device) return launch(c, nullptr, 1, W, H, 0, rows, out_rgba, static_cast<hipStream_t>(stream), sp);
+    rc = ensure_out(c, bytes);
+    if (rc != RM_OK) return rc;
+    rc = launch(c, nullptr, 1, W, H, 0, rows, c->d_out, c->stream, sp);
+    if (rc != RM_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out_rgba, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RM_OK;
 }
 

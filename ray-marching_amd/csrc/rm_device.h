@@ -40,9 +40,23 @@ struct RmLaunch {
     float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
     uint32_t max_iter;
     uint32_t W, H, row0, rows;
+    // Interleaved strips (multi-GPU tiling): when strip_rows != 0 the `rows` output rows are the
+    // concatenation of strips strip_first, strip_first + strip_stride, ... of strip_rows rows each.
+    uint32_t strip_rows, strip_first, strip_stride;
     float* out;                // rows*W*4 floats per frame
     unsigned long long* stats; // diagnostics (RM_OPT_WAVE_STATS): 4 x u64 per wave, or nullptr
     const uint32_t* order;     // nullptr: tiles in raster order; else dispatch slot -> tile id, per frame
     const rm_uniforms* frames; // nullptr: use `u`; else frames[blockIdx.z]
     rm_uniforms u;
 };
+
+// Framebuffer row (0 = top) of output row `ry` of this launch.
+#if defined(__HIPCC__)
+__device__ __forceinline__
+#else
+static inline
+#endif
+uint32_t rm_global_row(const RmLaunch& L, uint32_t ry) {
+    if (L.strip_rows == 0u) return L.row0 + ry;
+    return ((ry / L.strip_rows) * L.strip_stride + L.strip_first) * L.strip_rows + ry % L.strip_rows;
+}

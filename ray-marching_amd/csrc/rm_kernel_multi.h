@@ -244,7 +244,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_raypool_multi(RmLaunch L, 
         const uint32_t px = tx < L.W ? tx : L.W - 1u;
         const uint32_t ry = ty < L.rows ? ty : L.rows - 1u;
         sxy[p] = screen_x(px, L.W);
-        sxy[G::PIX + p] = screen_y(L.row0 + ry, L.H);
+        sxy[G::PIX + p] = screen_y(rm_global_row(L, ry), L.H);
     }
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64) void rm_tile_cost(RmLaunch L, uint32_t* cost) {
         const uint32_t tx = tile_x * G::TW + p % G::TW, ty = tile_y * G::TH + p / G::TW;
         const uint32_t px = tx < L.W ? tx : L.W - 1u, ry = ty < L.rows ? ty : L.rows - 1u;
         float dx, dy, dz;
-        gen_ray(u, ro, screen_x(px, L.W), screen_y(L.row0 + ry, L.H), 1u, 2u, dx, dy, dz);
+        gen_ray(u, ro, screen_x(px, L.W), screen_y(rm_global_row(L, ry), L.H), 1u, 2u, dx, dy, dz);
         const bool culled = (L.flags & 1u) && ray_misses_scene(cullt, L.n_cull, dx, dy, dz);
         n += (uint32_t)__popcll(__ballot(!culled));
     }

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void rm_render_queue(RmLaunch L) {
     // this lane's pixel: ray r of the pool belongs to pixel r & 63 (edge tiles clamp)
     const uint32_t tx = blockIdx.x * 8u + (lane & 7u), ty = blockIdx.y * 8u + (lane >> 3);
     const float my_sx = screen_x(tx < L.W ? tx : L.W - 1u, L.W);
-    const float my_sy = screen_y(L.row0 + (ty < L.rows ? ty : L.rows - 1u), L.H);
+    const float my_sy = screen_y(rm_global_row(L, ty < L.rows ? ty : L.rows - 1u), L.H);
 
     // lane state: evaluation point = b + d * sc
     float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;

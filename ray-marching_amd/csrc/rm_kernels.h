@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void rm_render_pixel(RmLaunch L) {
     const uint32_t px = blockIdx.x * 16u + lx;
     const uint32_t ry = blockIdx.y * 16u + ly;  // row inside the band
     if (px >= L.W || ry >= L.rows) return;       // no barrier after this point
-    const uint32_t py = L.row0 + ry;
+    const uint32_t py = rm_global_row(L, ry);
 
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);  // wgsl:39-40
     const float sx = screen_x(px, L.W), sy = screen_y(py, L.H);
@@ -272,7 +272,7 @@ __global__ __launch_bounds__(64) void rm_render_raypool(RmLaunch L, uint32_t ref
     const uint32_t px = tx < L.W ? tx : L.W - 1u;
     const uint32_t ry = ty < L.rows ? ty : L.rows - 1u;
     sxy[lane] = screen_x(px, L.W);
-    sxy[64u + lane] = screen_y(L.row0 + ry, L.H);
+    sxy[64u + lane] = screen_y(rm_global_row(L, ry), L.H);
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
         for (uint32_t k = lane; k < L.n_rec * 8u; k += 64u) lprog[k] = src[k];

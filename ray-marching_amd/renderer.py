@@ -90,6 +90,23 @@ class RayMarchingResources:
         self._check(self._L.rm_draw(self._h, W, H, row0, rows, C.c_void_p(out_ptr), 1,
                                     C.c_void_p(stream) if stream else None))
 
+    def draw_strips(self, W, H, strip_rows, first, stride):
+        """This GPU's interleaved strips of a W x H image (rm_draw_strips) -> (rows, W, 4) host array."""
+        from . import shard
+        rows = shard.strip_row_count(H, strip_rows, first, stride)
+        out = np.empty((rows, W, 4), dtype=np.float32)
+        n = C.c_uint32(0)
+        self._check(self._L.rm_draw_strips(self._h, W, H, strip_rows, first, stride,
+                                           out.ctypes.data_as(C.c_void_p) if rows else None, 0, None, C.byref(n)))
+        assert n.value == rows
+        return out
+
+    def draw_strips_device(self, W, H, strip_rows, first, stride, out_ptr, stream=None):
+        n = C.c_uint32(0)
+        self._check(self._L.rm_draw_strips(self._h, W, H, strip_rows, first, stride, C.c_void_p(out_ptr), 1,
+                                           C.c_void_p(stream) if stream else None, C.byref(n)))
+        return n.value
+
     def draw_batch(self, frames, W, H):
         arr = (Uniforms * len(frames))(*frames)
         out = np.empty((len(frames), H, W, 4), dtype=np.float32)

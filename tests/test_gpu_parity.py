@@ -210,6 +210,31 @@ def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
         assert_same(res.draw(W, H), oracle.render(u, lim, 0, [], W, H, threads=4))
 
 
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL,
+                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS],
+                         ids=["default", "pixel", "raypool", "multi2", "queue_lds"])
+def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
+    """rm_draw_strips: the multi-GPU tiling partition.  Every rank's strips, scattered back,
+    must reproduce the single-GPU frame byte for byte (tiling invariance)."""
+    from ray_marching_amd import shard
+    W, H = 120, 104       # 6.5 strips of 16 rows
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    lim = (0.01, 100.0, 96)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    full = res.draw(W, H)
+    assert_same(full, oracle.render(u, lim, cc, w, W, H, threads=4))
+    for world in (1, 2, 3, 8):
+        img = np.zeros_like(full)
+        for rank in range(world):
+            compact = res.draw_strips(W, H, 16, rank, world)
+            assert compact.shape[0] == shard.strip_row_count(H, 16, rank, world)
+            shard.scatter_strips(img, compact, H, rank, world, 16)
+        assert img.tobytes() == full.tobytes()
+    with pytest.raises(_ffi.RmError):
+        res.draw_strips(W, H, 12, 0, 2)          # strip height must be a multiple of 16
+    assert res.draw_strips(W, H, 32, 7, 8).shape[0] == 0   # more ranks than strips: empty share
+
+
 def test_raw_write_buffer_path_and_stale_tail(res, oracle):
     """prepare()'s literal call sequence (renderer.rs:213-239): raw byte writes; words beyond
     the current program are stale and must be ignored (renderer.rs:230-239 never clears)."""
