@@ -73,8 +73,27 @@ def build_host(force=False, verbose=False):
     return HOST_SO
 
 
+DROPIN_EXE = os.path.join(PKG, "dropin_test")
+
+
+def build_cpp_dropin(force=False, verbose=False):
+    """tests/cpp/dropin_test.cpp: the C++ host mirror linked against librm_hip.so (host-only C++)."""
+    src = os.path.join(ROOT, "tests", "cpp", "dropin_test.cpp")
+    build_hip(False, verbose)
+    if not force and not _newer(DROPIN_EXE, _sources(CSRC, INCLUDE) + [src]):
+        return DROPIN_EXE
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-ffp-contract=off", "-I", INCLUDE, "-I", CSRC,
+           "-o", DROPIN_EXE, src, "-L", PKG, "-lrm_hip", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return DROPIN_EXE
+
+
 def build_all(force=False, verbose=False):
-    return build_hip(force, verbose), build_host(force, verbose)
+    out = build_hip(force, verbose), build_host(force, verbose)
+    build_cpp_dropin(force, verbose)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,41 @@
+// dropin_test.cpp -- the C++ mirror of RayMarchingCallback (csrc/host/renderer.hpp) end to end on
+// the GPU, written the way main.rs:71-79 + renderer.rs:195-256 use the reference types.
+// Prints a checksum line that tests/test_gpu_cpp_dropin.py compares with the oracle.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "host/renderer.hpp"
+#include "host/scenes.hpp"
+
+using namespace ray_marching;
+
+int main(int argc, char** argv) {
+    const uint32_t W = 96, H = 64;
+    const char* out_path = argc > 1 ? argv[1] : nullptr;
+    try {
+        auto resources = RayMarchingResources::new_(0);
+        auto controller = OrbitCameraController::new_({0, 0, 0}, 5.0f);
+        controller.update(OrbitCameraControllerEvent::Orbit{{35.f, -25.f}});
+        auto cb = RayMarchingCallback::new_(0.0f, scenes::g8(), {(float)W, (float)H}, controller.camera());
+        cb.prepare(resources);
+        std::vector<float> image((size_t)W * H * 4);
+        cb.paint(resources, W, H, image.data());
+        if (out_path) {
+            FILE* f = std::fopen(out_path, "wb");
+            if (!f) return 3;
+            std::fwrite(image.data(), 4, image.size(), f);
+            std::fclose(f);
+        }
+        // None scene: cmd_count = 0 (renderer.rs:224-227)
+        auto none_cb = RayMarchingCallback::new_(0.0f, std::nullopt, {(float)W, (float)H}, controller.camera());
+        none_cb.prepare(resources);
+        none_cb.paint(resources, W, H, image.data());
+        std::printf("dropin ok %ux%u\n", W, H);
+    } catch (const RmException& e) {
+        std::fprintf(stderr, "rm error %d: %s\n", e.status, e.what());
+        return 2;
+    }
+    return 0;
+}
