@@ -100,7 +100,9 @@ enum rm_kernel {
     RM_KERNEL_MULTI2 = 6, RM_KERNEL_MULTI2_LDS = 7,
     RM_KERNEL_MULTI4 = 8, RM_KERNEL_MULTI4_LDS = 9,
     /* v4: ray pool with LDS ready/shade queues: ray generation, culling and shading run 64 rays at a time */
-    RM_KERNEL_QUEUE = 10, RM_KERNEL_QUEUE_LDS = 11
+    RM_KERNEL_QUEUE = 10, RM_KERNEL_QUEUE_LDS = 11,
+    /* v5: v3 with full-width ray production / shading through per-wave LDS rings and a sharper miss test */
+    RM_KERNEL_V5 = 12, RM_KERNEL_V5_LDS = 13
 };
 enum rm_info {
     RM_INFO_KERNEL_MS = 0,       /* duration of the last timed kernel launch, milliseconds */

@@ -36,6 +36,7 @@ RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0
 RM_KERNEL_MULTI1, RM_KERNEL_MULTI1_LDS, RM_KERNEL_MULTI2, RM_KERNEL_MULTI2_LDS = 4, 5, 6, 7
 RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
 RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
+RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT = 4, 5
 

@@ -17,6 +17,7 @@
 #include "rm_kernels.h"
 #include "rm_kernel_multi.h"
 #include "rm_kernel_queue.h"
+#include "rm_kernel_v5.h"
 
 #define RM_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -54,6 +55,7 @@ struct rm_ctx {
     // options / info
     int kernel = RM_KERNEL_DEFAULT;
     uint32_t refill_min = 8;
+    uint32_t refill_min_v5 = 1;
     bool cull = true;
     bool balance = true;
     int waves_per_tile = 4;
@@ -62,6 +64,8 @@ struct rm_ctx {
     size_t d_stats_bytes = 0, stats_valid_bytes = 0;
     uint32_t* d_cost = nullptr;   // per-tile cost estimates / dispatch order of the balance pre-pass
     uint32_t* d_order = nullptr;
+    uint32_t* d_counters = nullptr;  // v5: {work-list length, cursor} per frame
+    size_t d_counters_cap = 0;
     size_t d_tiles_cap = 0;
     bool timing = false;
     double last_kernel_ms = 0.0;
@@ -193,6 +197,78 @@ int launch_multi(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipS
     }
 }
 
+template <int WPT>
+int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
+    RmLaunch L = L_in;
+    bool cull = c->cull && L.n_rec <= 256u;
+    if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi_w
+    L.n_cull = cull ? L.n_rec : 0u;
+    L.flags = cull ? 1u : 0u;
+    const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
+    const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
+                         (size_t)L.spill_depth * 64u * WPT * 4u + (size_t)L.n_cull * sizeof(rmk::CullEntry) +
+                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
+    if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
+    // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
+    const size_t need = (size_t)n_tiles * n_frames;
+    if (need > c->d_tiles_cap) {
+        if (c->d_cost) (void)hipFree(c->d_cost);
+        if (c->d_order) (void)hipFree(c->d_order);
+        c->d_cost = c->d_order = nullptr;
+        c->d_tiles_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_cost, need * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc(&c->d_order, need * sizeof(uint32_t)));
+        c->d_tiles_cap = need;
+    }
+    if (n_frames > c->d_counters_cap) {
+        if (c->d_counters) (void)hipFree(c->d_counters);
+        c->d_counters = nullptr;
+        c->d_counters_cap = 0;
+        HIP_TRY(c, hipMalloc(&c->d_counters, (size_t)n_frames * 2u * sizeof(uint32_t)));
+        c->d_counters_cap = n_frames;
+    }
+    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3(n_tiles, 1, n_frames), dim3(64),
+                       (size_t)L.n_cull * sizeof(rmk::CullEntry), s, L, c->d_cost);
+    hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, c->d_counters,
+                       n_tiles, c->balance ? 1u : 0u);
+    rmk::V5Work work{c->d_order, c->d_counters};
+    // persistent grid: about as many workgroups as fit the chip (LDS, 32 waves per CU), never more than tiles
+    uint32_t per_cu = (uint32_t)std::min<size_t>(32u / WPT, (160u * 1024u) / shmem);
+    if (per_cu < 1u) per_cu = 1u;
+    const uint32_t n_wg = std::min<uint32_t>(n_tiles, (uint32_t)std::max(1, c->cu_count) * per_cu);
+    dim3 grid(n_wg, 1, n_frames);
+    if (c->wave_stats) {
+        const size_t sneed = (size_t)n_wg * n_frames * WPT * 4u * sizeof(unsigned long long);
+        if (sneed > c->d_stats_bytes) {
+            if (c->d_stats) (void)hipFree(c->d_stats);
+            c->d_stats = nullptr;
+            c->d_stats_bytes = 0;
+            HIP_TRY(c, hipMalloc(&c->d_stats, sneed));
+            c->d_stats_bytes = sneed;
+        }
+        c->stats_valid_bytes = sneed;
+        L.stats = c->d_stats;
+    }
+    if (lds)
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    else
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    return finish_launch(c, s);
+}
+
+int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
+    int wpt = c->waves_per_tile;
+    const size_t fixed = 4096u + (size_t)L.n_rec * (32u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
+    while (wpt > 1 && fixed + (size_t)wpt * ((4u * rmk::V5_RQ + 7u * rmk::V5_SQ) * 4u + (size_t)L.spill_depth * 256u) > 48u * 1024u)
+        wpt /= 2;
+    switch (wpt) {
+    case 1: return launch_v5_w<1>(c, L, lds, n_frames, s);
+    case 2: return launch_v5_w<2>(c, L, lds, n_frames, s);
+    case 8: return launch_v5_w<8>(c, L, lds, n_frames, s);
+    default: return launch_v5_w<4>(c, L, lds, n_frames, s);
+    }
+}
+
 int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
     RmLaunch L = L_in;
     bool cull = c->cull && L.n_rec <= 256u;
@@ -231,7 +307,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.stats = nullptr;
     L.u = c->uniforms;
     if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
-    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_MULTI1_LDS : c->kernel;
+    int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_V5_LDS : c->kernel;
     switch (kernel) {
     case RM_KERNEL_RAYPOOL:
     case RM_KERNEL_RAYPOOL_LDS: {
@@ -250,6 +326,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
         size_t shmem = (size_t)L.n_rec * sizeof(RmRecord) + (size_t)L.spill_depth * 256u * sizeof(float);
         hipLaunchKernelGGL(rmk::rm_render_pixel, grid, dim3(256), shmem, s, L);
     } break;
+    case RM_KERNEL_V5: case RM_KERNEL_V5_LDS: return launch_v5(c, L, kernel == RM_KERNEL_V5_LDS, n_frames, s);
     case RM_KERNEL_QUEUE: case RM_KERNEL_QUEUE_LDS: return launch_queue(c, L, kernel == RM_KERNEL_QUEUE_LDS, n_frames, s);
     case RM_KERNEL_MULTI1: case RM_KERNEL_MULTI1_LDS: return launch_multi<1>(c, L, kernel == RM_KERNEL_MULTI1_LDS, n_frames, s);
     case RM_KERNEL_MULTI2: case RM_KERNEL_MULTI2_LDS: return launch_multi<2>(c, L, kernel == RM_KERNEL_MULTI2_LDS, n_frames, s);
@@ -345,6 +422,7 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_cost) (void)hipFree(c->d_cost);
     if (c->d_order) (void)hipFree(c->d_order);
+    if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -536,7 +614,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     if (!c) return RM_ERR_NULL;
     switch (key) {
     case RM_OPT_KERNEL:
-        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_QUEUE_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_V5_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = (int)value;
         return RM_OK;
     case RM_OPT_TIMING: c->timing = value != 0; return RM_OK;
@@ -551,6 +629,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [1,64]", (long long)value);
         c->refill_min = (uint32_t)value;
+        c->refill_min_v5 = (uint32_t)value;
         return RM_OK;
     default: return fail(c, RM_ERR_ARG, "unknown option %d", key);
     }

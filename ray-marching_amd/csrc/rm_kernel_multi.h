@@ -77,6 +77,10 @@ RM_DEV float sdf_box_t(float px, float py, float pz, const float (&p)[7], uint32
 template <int R, bool FAST>
 RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R], const float (&qy)[R],
                          const float (&qz)[R], float (&acc)[R], float* spill, uint32_t& sp, uint32_t& tiny) {
+    // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
+    // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
+    // wait for the NEXT record's LDS read before starting the current record's arithmetic.
+    op = __builtin_amdgcn_readfirstlane(op);
     const uint32_t kind = op & 3u, mode = (op >> 2) & 3u;
     float a[R], b[R];
     if (kind == RM_KIND_POP) {

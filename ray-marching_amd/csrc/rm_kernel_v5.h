@@ -1,0 +1,461 @@
+// rm_kernel_v5.h -- kernel v5 "streamed ray pool" (gfx950, wave64).  Device code only.
+//
+// One workgroup of WPT waves owns an 8x8-pixel tile and the pool of its 1024 rays (as in v3).
+// What changes is WHERE the expensive, branchy per-ray work runs:
+//
+//   produce  Ray generation (2 mat-vec + vec4 normalize: wgsl:52-62) and the exact miss test run
+//            for 64 consecutive rays of the pool at a time with ALL lanes active, using scratch
+//            registers only (the marching state of the lanes is not touched).  Rays that provably
+//            miss the scene are shaded on the spot (res[r] = floor code); survivors are compacted
+//            with ballot + prefix count into a per-wave READY ring in LDS (ray id + direction).
+//   consume  A lane whose ray ended pops the next ready ray: four LDS reads.
+//   shade    A finished ray pushes its shading inputs (hit: normal sum + position, miss:
+//            direction) into a per-wave SHADE ring; it is flushed (all waiting entries shaded at
+//            once, 2 normalizes = 6 correctly rounded divides + 2 sqrt per hit) when the next push
+//            would not fit.
+//
+// In v3 these pieces ran inside the march loop under a sparse exec mask (typically 8-14 of 64
+// lanes) and cost ~25 % of all vector instructions; here they run at (nearly) full occupancy and
+// the march loop is: evaluation point, map_scene, ~20 VALU of state update, three ballots.
+// Both rings are private to a wave (no barrier; LDS executes a wave's accesses in order), the
+// pool cursor and the result array are shared by the tile's waves.
+//
+// The miss test is also sharper than v3's: boxes use a ray/slab test against the box inflated by
+// the margin instead of a bounding-sphere cone, and the margin is min_dist + 1e-4 of the local
+// coordinate scale (float error of positions and SDF values is ~1e-6 of that scale).
+#pragma once
+#include "rm_kernel_multi.h"
+
+namespace rmk {
+
+constexpr uint32_t V5_RQ = 128u;  // ready ring entries per wave (a produce round adds <= 64 to < 64)
+constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
+
+// Cull table entry of one command: 32 bytes.
+//   tag 0 (sphere): a = (m.x, m.y, m.z, s)   ray clears it iff  m.d - s < 0          (cone, see v3)
+//   tag 1 (box)   : a.xyz = lo - o, b.xyz = hi - o of the box inflated by the margin (slab test)
+//   tag 2         : operator, constrains nothing;   tag 3: veto (nothing may be culled)
+struct CullEntry {
+    float4 a, b;
+};
+
+RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, float min_dist) {
+    const float scale = 1.0f + __builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz) + rho +
+                        __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
+    return fmax_(min_dist, 0.0f) * 1.01f + 1.0e-4f * scale;
+}
+
+RM_DEV CullEntry cull_entry_v5(const RmRecord& rec, const V4& ro, float min_dist) {
+    const uint32_t kind = rec.op & 3u;
+    const float inf = __uint_as_float(0x7F800000u);
+    CullEntry e;
+    e.a = make_float4(0.0f, 0.0f, 0.0f, inf);
+    e.b = make_float4(0.0f, 0.0f, 0.0f, 2.0f);
+    if (kind == RM_KIND_POP) return e;
+    const float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2];
+    bool finite = __builtin_fabsf(cx) < inf && __builtin_fabsf(cy) < inf && __builtin_fabsf(cz) < inf &&
+                  __builtin_fabsf(ro.x) < inf && __builtin_fabsf(ro.y) < inf && __builtin_fabsf(ro.z) < inf &&
+                  __builtin_fabsf(min_dist) < inf;
+    if (kind == RM_KIND_SPHERE) {
+        const float rho = fmax_(rec.p[3], 0.0f);
+        finite = finite && rho < inf;
+        const float Rk = rho + cull_margin(cx, cy, cz, rho, ro, min_dist);
+        const float mx = cx - ro.x, my = cy - ro.y, mz = cz - ro.z;
+        const float mm = mx * mx + my * my + mz * mz;
+        // s < sqrt(|m|^2 - Rk^2), the slack covering the rounding of this computation and of the
+        // per-ray dot product (|error| <= ~4e-7 |m|)
+        const float lim = mm * (1.0f - 4.0e-6f) - Rk * Rk * (1.0f + 4.0e-6f);
+        float s = -inf;  // origin inside (or not clearly outside) the inflated sphere: never clear
+        if (lim > 0.0f && lim < inf) s = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
+        e.a = make_float4(mx, my, mz, s);
+        e.b.w = 0.0f;
+    } else {
+        const float hx = fmax_(rec.p[3], 0.0f), hy = fmax_(rec.p[4], 0.0f), hz = fmax_(rec.p[5], 0.0f);
+        finite = finite && hx < inf && hy < inf && hz < inf;
+        const float rho = hx + hy + hz;
+        const float M = cull_margin(cx, cy, cz, rho, ro, min_dist);
+        e.a = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
+        e.b = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 1.0f);
+    }
+    if (!finite) e.b.w = 3.0f;
+    return e;
+}
+
+// true iff the half-line o + t d (t >= 0) provably stays clear of every primitive's margin zone.
+RM_DEV bool ray_misses_scene_v5(const CullEntry* tab, uint32_t n, float dx, float dy, float dz) {
+    // 1/d with |d_i| clamped away from 0 so that no 0 * inf = NaN can appear in the slab test
+    const float tiny = 1.0e-30f;
+    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dx), tiny), dx));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dy), tiny), dy));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dz), tiny), dz));
+    bool clear = true;  // n == 0 (empty scene): every ray misses (wgsl:189-191)
+    for (uint32_t k = 0; k < n; k++) {
+        const float4 a = tab[k].a, b = tab[k].b;  // wave-uniform address: LDS broadcast
+        const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)b.w);
+        if (tag == 0u) {
+            const float t = __builtin_fmaf(a.z, dz, __builtin_fmaf(a.y, dy, __builtin_fmaf(a.x, dx, -a.w)));
+            clear = clear && (t < 0.0f);  // NaN -> not clear
+        } else if (tag == 1u) {
+            const float x1 = a.x * ix, x2 = b.x * ix, y1 = a.y * iy, y2 = b.y * iy, z1 = a.z * iz, z2 = b.z * iz;
+            const float tn = fmax_(fmin_(x1, x2), fmax_(fmin_(y1, y2), fmin_(z1, z2)));
+            const float tf = fmin_(fmax_(x1, x2), fmin_(fmax_(y1, y2), fmax_(z1, z2)));
+            const bool hits_box = tf >= fmax_(tn, 0.0f);  // a dropped NaN only widens the interval
+            clear = clear && !hits_box;
+        } else if (tag == 3u) {
+            clear = false;
+        }
+        if (__ballot(clear) == 0ull) break;
+    }
+    return clear;
+}
+
+// Work list produced by the pre-pass (rm_tile_pre_v5 + rm_tile_sort_v5), one per frame.
+struct V5Work {
+    const uint32_t* order;  // [n_frames][n_tiles] ids of the tiles that need marching, heaviest first
+    uint32_t* counters;     // [n_frames][2]: {number of such tiles, cursor of the persistent workgroups}
+};
+
+// Persistent workgroups: the grid holds about as many workgroups as the chip has room for; each
+// takes the next tile of the work list with one atomic and leaves when the list is exhausted
+// (no spinning, no inter-workgroup dependency).  Tiles whose 1024 rays are all culled never reach
+// this kernel: the pre-pass writes their pixels directly.
+template <class Prog, bool PROG_IN_LDS, int WPT>
+__global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
+    constexpr uint32_t POOL = 1024u;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
+    float* res = reinterpret_cast<float*>(smem);                       // [1024] result code per ray (tile)
+    uint32_t* wbase = smem + POOL + wave * (4u * V5_RQ + 7u * V5_SQ);  // this wave's rings
+    uint32_t* rq_rid = wbase;                                          // ready ring (SoA)
+    float* rq_d = reinterpret_cast<float*>(wbase + V5_RQ);             // [3][V5_RQ]
+    uint32_t* sq_rid = wbase + 4u * V5_RQ;                             // shade ring: rid | hit << 31
+    float* sq_v = reinterpret_cast<float*>(sq_rid + V5_SQ);            // [6][V5_SQ]
+    uint32_t* after = smem + POOL + WPT * (4u * V5_RQ + 7u * V5_SQ);
+    float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
+    CullEntry* cullt = reinterpret_cast<CullEntry*>(after + WPT * L.spill_depth * 64u);    // [n_cull]
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(cullt + L.n_cull);
+    uint32_t* s_next = lprog + (PROG_IN_LDS ? L.n_rec * 8u : 0u);      // shared pool cursor
+    uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
+
+    rm_uniforms u = L.u;
+    if (L.frames) u = L.frames[blockIdx.z];  // wave-uniform
+    float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
+    const uint32_t tiles_x = (L.W + 7u) / 8u;
+    const uint32_t* order = work.order + (size_t)blockIdx.z * n_tiles;
+    uint32_t* counters = work.counters + 2u * blockIdx.z;
+    const uint32_t n_active = counters[0];
+
+    const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);  // wgsl:39-40
+    const float eps = 0.0001f;                                    // wgsl:136
+    if (PROG_IN_LDS) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
+        for (uint32_t k = tid; k < L.n_rec * 8u; k += 64u * WPT) lprog[k] = src[k];
+    }
+    for (uint32_t k = tid; k < L.n_cull; k += 64u * WPT) cullt[k] = cull_entry_v5(L.prog[k], ro, L.min_dist);
+
+    Prog prog;
+    if constexpr (PROG_IN_LDS) prog.base = lprog;
+    else prog.base = L.prog;
+
+    const unsigned long long t_start = L.stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    uint32_t n_iter = 0u, n_live = 0u, n_prod = 0u, n_tiles_done = 0u;
+
+  for (;;) {  // ---- next tile of the work list ----
+    if (tid == 0u) {
+        *s_tile = atomicAdd(&counters[1], 1u);
+        *s_next = 0u;
+    }
+    __syncthreads();
+    const uint32_t slot = *s_tile;
+    if (slot >= n_active) break;
+    const uint32_t tile = order[slot];
+    const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
+    n_tiles_done++;
+
+    // Ray r of the pool: pixel r & 63 (== this lane in a produce round), AA sample r >> 6.
+    const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
+    const float my_sx = screen_x(tx < L.W ? tx : L.W - 1u, L.W);                                   // edge tiles clamp
+    const float my_sy = screen_y(rm_global_row(L, ty < L.rows ? ty : L.rows - 1u), L.H);
+
+    // lane state: evaluation point = b + d * sc
+    float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
+    uint32_t it = 0u, rid = 0u, mode = M_EMPTY;
+    uint32_t rq_head = 0u, rq_tail = 0u, sq_n = 0u;  // wave-uniform ring cursors
+    bool pool_open = true;                           // wave-uniform: the shared pool may still hold rays
+
+    auto flush_shade = [&]() {  // shade every waiting entry (<= 64): one lane per entry
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane < sq_n) {
+            const uint32_t tag = sq_rid[lane];
+            const float a0 = sq_v[lane], a1 = sq_v[V5_SQ + lane], a2 = sq_v[2u * V5_SQ + lane];
+            float code;
+            if (tag >> 31) {  // hit: wgsl:98-103
+                code = shade_hit(a0, a1, a2, sq_v[3u * V5_SQ + lane], sq_v[4u * V5_SQ + lane], sq_v[5u * V5_SQ + lane]);
+            } else {  // marched without a hit: floor / black, wgsl:117-130
+                code = miss_code(ro, a0, a1, a2);
+            }
+            res[tag & 0x7FFFFFFFu] = code;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        sq_n = 0u;
+    };
+
+    for (;;) {
+        // ---- A. idle lanes take ready rays; the ring is topped up 64 candidates at a time ----
+        const unsigned long long want = __ballot(mode == M_EMPTY);
+        const unsigned long long live0 = __ballot(mode < M_DONE_HIT);
+        const uint32_t n_want = (uint32_t)__popcll(want);
+        if (n_want != 0u && (live0 == 0ull || n_want >= refill_min)) {
+            while (rq_tail - rq_head < n_want && pool_open) {
+                uint32_t base = 0u;
+                if (lane == 0u) base = atomicAdd(s_next, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (base >= POOL) { pool_open = false; break; }
+                n_prod++;
+                const uint32_t r = base + lane, s = base >> 6;
+                float gx, gy, gz;
+                gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
+                const bool culled = L.max_iter == 0u ||
+                                    ((L.flags & 1u) && ray_misses_scene_v5(cullt, L.n_cull, gx, gy, gz));
+                if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
+                const unsigned long long keep = __ballot(!culled);
+                if (!culled) {
+                    const uint32_t e = (rq_tail + lane_rank(keep)) & (V5_RQ - 1u);
+                    rq_rid[e] = r;
+                    rq_d[e] = gx; rq_d[V5_RQ + e] = gy; rq_d[2u * V5_RQ + e] = gz;
+                }
+                rq_tail += (uint32_t)__popcll(keep);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t avail = rq_tail - rq_head;
+            if (mode == M_EMPTY) {
+                const uint32_t rank = lane_rank(want);
+                if (rank < avail) {
+                    const uint32_t e = (rq_head + rank) & (V5_RQ - 1u);
+                    rid = rq_rid[e];
+                    dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
+                    bx = ro.x; by = ro.y; bz = ro.z;
+                    sc = 0.0f;  // dist (wgsl:88)
+                    it = 0u;
+                    mode = M_MARCH;
+                } else if (!pool_open) {
+                    mode = M_RETIRED;  // pool exhausted and ring drained
+                }
+            }
+            rq_head += n_want < avail ? n_want : avail;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        const unsigned long long live = __ballot(mode < M_DONE_HIT);
+        if (live == 0ull) {
+            if (__ballot(mode == M_EMPTY) == 0ull) break;  // every lane retired
+            continue;                                       // idle lanes remain: force a refill round
+        }
+
+        // ---- B. one map_scene evaluation per live lane ----
+        n_iter++;
+        n_live += (uint32_t)__popcll(live);
+        uint32_t fin = 0u;  // 1: finished with a hit, 2: finished without
+        {
+            float qx[1], qy[1], qz[1], v[1];
+            qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
+            uint32_t tiny = 0xFFFFFFFFu;
+            map_scene_multi<1, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
+                map_scene_multi<1, false>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            const float sd = v[0];
+            if (mode == M_MARCH) {
+                if (sd < L.min_dist) {  // wgsl:97: hit -> normal taps around pos = q
+                    bx = qx[0]; by = qy[0]; bz = qz[0];
+                    sc = eps;
+                    uint32_t sx, sy, sz;
+                    tap_signs(0u, sx, sy, sz);
+                    dx = __uint_as_float(0x3F800000u ^ sx);
+                    dy = __uint_as_float(0x3F800000u ^ sy);
+                    dz = __uint_as_float(0x3F800000u ^ sz);
+                    mode = M_TAP0;
+                } else if (sd > L.max_dist) {  // wgsl:109-111
+                    fin = 2u;
+                } else {
+                    sc += sd;  // wgsl:114
+                    it += 1u;
+                    if (it >= L.max_iter) fin = 2u;  // loop bound, wgsl:90
+                }
+            } else if (mode < M_DONE_HIT) {
+                const uint32_t t = mode - M_TAP0;  // tap t: n (+)= k_t * f; products with +-1 are exact
+                uint32_t sx, sy, sz;
+                tap_signs(t, sx, sy, sz);
+                const float vx = __uint_as_float(__float_as_uint(sd) ^ sx);
+                const float vy = __uint_as_float(__float_as_uint(sd) ^ sy);
+                const float vz = __uint_as_float(__float_as_uint(sd) ^ sz);
+                nx = t == 0u ? vx : nx + vx;
+                ny = t == 0u ? vy : ny + vy;
+                nz = t == 0u ? vz : nz + vz;
+                tap_signs(t + 1u, sx, sy, sz);
+                dx = __uint_as_float(0x3F800000u ^ sx);
+                dy = __uint_as_float(0x3F800000u ^ sy);
+                dz = __uint_as_float(0x3F800000u ^ sz);
+                mode += 1u;
+                if (mode == M_DONE_HIT) fin = 1u;
+            }
+        }
+
+        // ---- C. finished rays -> shade ring; the lane becomes idle ----
+        const unsigned long long fin_mask = __ballot(fin != 0u);
+        if (fin_mask != 0ull) {
+            const uint32_t n_fin = (uint32_t)__popcll(fin_mask);
+            if (sq_n + n_fin > V5_SQ) flush_shade();
+            if (fin != 0u) {
+                const uint32_t e = sq_n + lane_rank(fin_mask);
+                if (fin == 1u) {
+                    sq_rid[e] = rid | 0x80000000u;
+                    sq_v[e] = nx; sq_v[V5_SQ + e] = ny; sq_v[2u * V5_SQ + e] = nz;
+                    sq_v[3u * V5_SQ + e] = bx; sq_v[4u * V5_SQ + e] = by; sq_v[5u * V5_SQ + e] = bz;
+                } else {
+                    sq_rid[e] = rid;
+                    sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
+                }
+                mode = M_EMPTY;
+            }
+            sq_n += n_fin;
+        }
+    }
+    if (sq_n != 0u) flush_shade();
+    __syncthreads();  // all waves of the tile are done: res[] is complete
+
+    // ---- resolve: one pixel per thread, samples in the reference order (wgsl:44-45, 68-69) ----
+    for (uint32_t p = tid; p < 64u; p += 64u * WPT) {
+        const uint32_t px = tile_x * 8u + (p & 7u), py = tile_y * 8u + (p >> 3);
+        if (px < L.W && py < L.rows) {
+            float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+#pragma unroll 4
+            for (uint32_t s = 0; s < 16u; s++) {
+                const float code = res[s * 64u + p];
+                float cr, cg, cb;
+                if (code >= 0.0f) {  // hit: (0.4,0.7,0.1) * k  (wgsl:105)
+                    cr = 0.4f * code; cg = 0.7f * code; cb = 0.1f * code;
+                } else if (code > -2.5f) {  // floor (wgsl:127)
+                    const float g = 0.2f * (-1.0f - code);
+                    cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
+                } else {
+                    cr = 0.0f; cg = 0.0f; cb = 0.0f;  // wgsl:130
+                }
+                tr += __builtin_sqrtf(cr);
+                tg += __builtin_sqrtf(cg);
+                tb += __builtin_sqrtf(cb);
+            }
+            float4 o;
+            o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
+            reinterpret_cast<float4*>(out)[(size_t)py * L.W + px] = o;
+        }
+    }
+    __syncthreads();  // res[] / rings / cursor are reused by the next tile
+  }
+    if (L.stats && lane == 0u) {
+        unsigned long long* st = L.stats + 4ull * (((size_t)blockIdx.z * gridDim.x + blockIdx.x) * WPT + wave);
+        st[0] = t_start;
+        st[1] = __builtin_amdgcn_s_memrealtime();
+        st[2] = ((unsigned long long)n_tiles_done << 32) | n_iter;
+        st[3] = ((unsigned long long)n_prod << 32) | n_live;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pre-pass, one wave per tile, lane = pixel.  Walks the 16 AA samples in reference order and
+// stops at the first sample with a ray that cannot be culled: that tile goes on the work list
+// (cost = how many of that sample's 64 rays survive).  If ALL 1024 rays are provably misses the
+// tile is finished here: every lane has summed its pixel's 16 gamma-corrected floor colours in
+// the reference's order (wgsl:44-45, 68-69, 73-75), writes the pixel and reports cost 0.
+// ~60 % of the tiles of the metric frame end this way and never occupy a marching workgroup.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    CullEntry* cullt = reinterpret_cast<CullEntry*>(smem);
+    const uint32_t lane = threadIdx.x;
+    rm_uniforms u = L.u;
+    if (L.frames) u = L.frames[blockIdx.z];
+    float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
+    const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
+    for (uint32_t k = lane; k < L.n_cull; k += 64u) cullt[k] = cull_entry_v5(L.prog[k], ro, L.min_dist);
+    __syncthreads();
+    const uint32_t tiles_x = (L.W + 7u) / 8u;
+    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+    const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
+    const uint32_t px = tx < L.W ? tx : L.W - 1u, ry = ty < L.rows ? ty : L.rows - 1u;
+    const float sx = screen_x(px, L.W), sy = screen_y(rm_global_row(L, ry), L.H);
+    const bool may_cull = (L.flags & 1u) != 0u || L.max_iter == 0u;
+    uint32_t survivors = 64u;
+    float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+    if (may_cull) {
+        survivors = 0u;
+        for (uint32_t s = 0; s < 16u; s++) {
+            float dx, dy, dz;
+            gen_ray(u, ro, sx, sy, s >> 2, s & 3u, dx, dy, dz);
+            const bool culled = L.max_iter == 0u || ray_misses_scene_v5(cullt, L.n_cull, dx, dy, dz);
+            survivors = (uint32_t)__popcll(__ballot(!culled));
+            if (survivors != 0u) break;
+            const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
+            float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+            if (c >= 0) {
+                const float g = 0.2f * (float)c;
+                cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
+            }
+            tr += __builtin_sqrtf(cr);
+            tg += __builtin_sqrtf(cg);
+            tb += __builtin_sqrtf(cb);
+        }
+    }
+    if (survivors == 0u && tx < L.W && ty < L.rows) {
+        float4 o;
+        o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;
+        reinterpret_cast<float4*>(out)[(size_t)ty * L.W + tx] = o;
+    }
+    if (lane == 0u) cost[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = survivors;  // 0 = done, else 1..64
+}
+
+// Work list of one frame (blockIdx.x = frame): ids of the tiles with cost > 0, by descending cost
+// when `balance` is set.  Also resets the persistent kernel's cursor.
+__global__ __launch_bounds__(1024) void rm_tile_sort_v5(const uint32_t* cost, uint32_t* order, uint32_t* counters,
+                                                        uint32_t n_tiles, uint32_t balance) {
+    __shared__ uint32_t hist[65], base[65];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* c = cost + (size_t)blockIdx.x * n_tiles;
+    uint32_t* o = order + (size_t)blockIdx.x * n_tiles;
+    if (tid < 65u) hist[tid] = 0u;
+    __syncthreads();
+    // bucket 0 = heaviest (cost 64) ... bucket 63 = cost 1; cost 0 (finished in the pre-pass) is dropped
+    auto bucket = [&](uint32_t v) { return balance ? 64u - (v < 64u ? v : 64u) : 0u; };
+    for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u) {
+        const uint32_t i = i0 + tid;
+        const uint32_t v = i < n_tiles ? c[i] : 0u;
+        // most active tiles have the same cost (64): count those once per wave, not once per lane
+        const unsigned long long heavy = __ballot(v != 0u && bucket(v) == 0u);
+        if (heavy != 0ull && (tid & 63u) == (uint32_t)__builtin_ctzll(heavy)) atomicAdd(&hist[0], (uint32_t)__popcll(heavy));
+        if (v != 0u && bucket(v) != 0u) atomicAdd(&hist[bucket(v)], 1u);
+    }
+    __syncthreads();
+    if (tid == 0u) {
+        uint32_t acc = 0u;
+        for (uint32_t b = 0; b < 65u; b++) { base[b] = acc; acc += hist[b]; }
+        counters[2u * blockIdx.x] = acc;      // tiles on the work list
+        counters[2u * blockIdx.x + 1u] = 0u;  // cursor
+    }
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u) {
+        const uint32_t i = i0 + tid;
+        const uint32_t v = i < n_tiles ? c[i] : 0u;
+        const bool is_heavy = v != 0u && bucket(v) == 0u;
+        const unsigned long long heavy = __ballot(is_heavy);
+        uint32_t pos0 = 0u;
+        if (heavy != 0ull) {
+            const int leader = __builtin_ctzll(heavy);
+            if ((int)(tid & 63u) == leader) pos0 = atomicAdd(&base[0], (uint32_t)__popcll(heavy));
+            pos0 = __shfl(pos0, leader);
+        }
+        if (is_heavy) o[pos0 + lane_rank(heavy)] = i;
+        else if (v != 0u) o[atomicAdd(&base[bucket(v)], 1u)] = i;
+    }
+}
+
+}  // namespace rmk

@@ -94,7 +94,7 @@ struct ProgLds {
     RM_DEV void load(uint32_t c, uint32_t& op, float (&p)[7]) const {
         const uint4* q = reinterpret_cast<const uint4*>(base + c * 8);
         uint4 a = q[0], b = q[1];
-        op = __builtin_amdgcn_readfirstlane(a.x);
+        op = a.x;  // made scalar (readfirstlane) by the consumer, see exec_command / map_scene
         p[0] = __uint_as_float(a.y); p[1] = __uint_as_float(a.z); p[2] = __uint_as_float(a.w);
         p[3] = __uint_as_float(b.x); p[4] = __uint_as_float(b.y); p[5] = __uint_as_float(b.z);
         p[6] = __uint_as_float(b.w);
@@ -131,6 +131,7 @@ RM_DEV float map_scene(const Prog& prog, uint32_t n_rec, const SpillLds& st, flo
         uint32_t op;
         float p[7];
         prog.load(c, op, p);
+        op = __builtin_amdgcn_readfirstlane(op);
         const uint32_t kind = op & 3u, mode = (op >> 2) & 3u;
         float a, b;
         if (kind == RM_KIND_POP) {

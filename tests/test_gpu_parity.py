@@ -17,9 +17,10 @@ pytestmark = pytest.mark.gpu
 TOLERANCE = 1e-4      # contract (BASELINE.json north_star); asserted bit-exact below
 KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_LDS,
            _ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_MULTI2_LDS,
-           _ffi.RM_KERNEL_MULTI4, _ffi.RM_KERNEL_MULTI4_LDS, _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS]
+           _ffi.RM_KERNEL_MULTI4, _ffi.RM_KERNEL_MULTI4_LDS, _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS,
+           _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]
 KERNEL_IDS = ["pixel", "raypool", "raypool_lds", "multi1", "multi1_lds", "multi2", "multi2_lds", "multi4",
-              "multi4_lds", "queue", "queue_lds"]
+              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds"]
 IDX = G.index()
 
 
@@ -162,8 +163,9 @@ CULL_CAMERAS = {
 
 @pytest.mark.parametrize("cam", sorted(CULL_CAMERAS))
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2,
-                                    _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS],
-                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds"])
+                                    _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5,
+                                    _ffi.RM_KERNEL_V5_LDS],
+                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds"])
 def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
     """The bounding-cone shortcut must never change a pixel: culling on == culling off == oracle,
     for cameras outside, inside, far from and grazing the scene, and for several min_dist."""
@@ -211,8 +213,8 @@ def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
 
 
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL,
-                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS],
-                         ids=["default", "pixel", "raypool", "multi2", "queue_lds"])
+                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS],
+                         ids=["default", "pixel", "raypool", "multi2", "queue_lds", "v5_lds"])
 def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     """rm_draw_strips: the multi-GPU tiling partition.  Every rank's strips, scattered back,
     must reproduce the single-GPU frame byte for byte (tiling invariance)."""
