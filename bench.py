@@ -41,6 +41,9 @@ def parse():
     p.add_argument("--mode", choices=["frames", "tile"], default="frames",
                    help="frames: every rank renders whole frames (weak scaling, default); tile: ONE frame per step "
                         "is tiled over the ranks in interleaved 16-row strips (strong scaling, north-star layout)")
+    p.add_argument("--dist-backend", default="nccl", help="process-group backend for the timing barrier (nccl = RCCL)")
+    p.add_argument("--all-ranks-on-device0", action="store_true",
+                   help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
@@ -94,9 +97,14 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    if args.all_ranks_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.dist_backend)
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     W, H = args.width, args.height
@@ -170,7 +178,8 @@ def main():
     elapsed = t1 - t0
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kernel_ms], dtype=torch.float64,
+                         device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms = float(t[0]), float(t[1])
 

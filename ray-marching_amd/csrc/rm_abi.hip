@@ -205,8 +205,10 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     L.n_cull = cull ? L.n_rec : 0u;
     L.flags = cull ? 1u : 0u;
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
+    if (!cull) L.n_cone = L.n_slab = 0u;
+    const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 32u;
     const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
-                         (size_t)L.spill_depth * 64u * WPT * 4u + (size_t)L.n_cull * sizeof(rmk::CullEntry) +
+                         (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
@@ -227,8 +229,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         HIP_TRY(c, hipMalloc(&c->d_counters, (size_t)n_frames * 2u * sizeof(uint32_t)));
         c->d_counters_cap = n_frames;
     }
-    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3(n_tiles, 1, n_frames), dim3(64),
-                       (size_t)L.n_cull * sizeof(rmk::CullEntry), s, L, c->d_cost);
+    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames), dim3(256),
+                       (size_t)(1024u + 4u) * 4u + cull_bytes, s, L, c->d_cost, n_tiles);
     hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, c->d_counters,
                        n_tiles, c->balance ? 1u : 0u);
     rmk::V5Work work{c->d_order, c->d_counters};
@@ -297,6 +299,8 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.spill_depth = c->decoded.spill_depth;
     L.n_cull = 0;
     L.flags = 0;
+    L.n_cone = c->decoded.n_sphere;
+    L.n_slab = c->decoded.n_box;
     L.min_dist = c->limits.min_dist;
     L.max_dist = c->limits.max_dist;
     L.max_iter = c->limits.max_iter;

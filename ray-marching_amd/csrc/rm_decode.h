@@ -13,6 +13,7 @@ struct RmDecoded {
     uint32_t n_words = 0;      // words consumed by cmd_count commands
     uint32_t max_depth = 0;    // value-stack depth of the reference machine
     uint32_t spill_depth = 0;  // LDS slots the accumulator machine needs
+    uint32_t n_sphere = 0, n_box = 0;  // primitives per kind; RmRecord::p[6] holds each one's slot within its kind
 };
 
 // Returns RM_OK or a negative rm_status.  `cap_words` is the number of u32 words that
@@ -35,6 +36,8 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             std::memcpy(r.p, words + ptr, np * 4);
             ptr += np;
             uint32_t kind = op == RM_CMD_SPHERE ? RM_KIND_SPHERE : RM_KIND_BOX;
+            const uint32_t slot = op == RM_CMD_SPHERE ? d.n_sphere++ : d.n_box++;
+            std::memcpy(&r.p[6], &slot, 4);  // slot in the kernels' per-kind miss-test tables
             // Fuse with a directly following binary operator: its rhs is this leaf.
             uint32_t mode = RM_MODE_PUSH;
             if (i + 1 < cmd_count && ptr < cap_words && depth >= 1) {

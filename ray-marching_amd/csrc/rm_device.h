@@ -37,6 +37,7 @@ struct RmLaunch {
     uint32_t spill_depth;      // LDS value-stack slots per lane this program needs
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
     uint32_t flags;            // bit 0: miss-ray culling enabled
+    uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / boxes of the program
     float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
     uint32_t max_iter;
     uint32_t W, H, row0, rows;

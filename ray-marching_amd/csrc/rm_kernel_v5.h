@@ -31,12 +31,16 @@ namespace rmk {
 constexpr uint32_t V5_RQ = 128u;  // ready ring entries per wave (a produce round adds <= 64 to < 64)
 constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
 
-// Cull table entry of one command: 32 bytes.
-//   tag 0 (sphere): a = (m.x, m.y, m.z, s)   ray clears it iff  m.d - s < 0          (cone, see v3)
-//   tag 1 (box)   : a.xyz = lo - o, b.xyz = hi - o of the box inflated by the margin (slab test)
-//   tag 2         : operator, constrains nothing;   tag 3: veto (nothing may be culled)
-struct CullEntry {
-    float4 a, b;
+// Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
+// decoder stores each primitive's slot within its kind in RmRecord::p[6]):
+//   cone[n_cone]  one float4 per sphere: (m.x, m.y, m.z, s); a ray clears it iff m.d - s < 0
+//   slab[n_slab]  two float4 per box: lo - o and hi - o of the box inflated by the margin
+//   veto          set when anything is non-finite: then nothing is culled
+struct CullTables {
+    const float4* cone;
+    const float4* slab;
+    const uint32_t* veto;
+    uint32_t n_cone, n_slab;
 };
 
 RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, float min_dist) {
@@ -45,13 +49,12 @@ RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, 
     return fmax_(min_dist, 0.0f) * 1.01f + 1.0e-4f * scale;
 }
 
-RM_DEV CullEntry cull_entry_v5(const RmRecord& rec, const V4& ro, float min_dist) {
+// Table entry (or entries) of one record; no-op for operators.  Called once per record per workgroup.
+RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, float4* cone, float4* slab, uint32_t* veto) {
     const uint32_t kind = rec.op & 3u;
+    if (kind == RM_KIND_POP) return;
     const float inf = __uint_as_float(0x7F800000u);
-    CullEntry e;
-    e.a = make_float4(0.0f, 0.0f, 0.0f, inf);
-    e.b = make_float4(0.0f, 0.0f, 0.0f, 2.0f);
-    if (kind == RM_KIND_POP) return e;
+    const uint32_t slot = __float_as_uint(rec.p[6]);
     const float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2];
     bool finite = __builtin_fabsf(cx) < inf && __builtin_fabsf(cy) < inf && __builtin_fabsf(cz) < inf &&
                   __builtin_fabsf(ro.x) < inf && __builtin_fabsf(ro.y) < inf && __builtin_fabsf(ro.z) < inf &&
@@ -65,46 +68,41 @@ RM_DEV CullEntry cull_entry_v5(const RmRecord& rec, const V4& ro, float min_dist
         // s < sqrt(|m|^2 - Rk^2), the slack covering the rounding of this computation and of the
         // per-ray dot product (|error| <= ~4e-7 |m|)
         const float lim = mm * (1.0f - 4.0e-6f) - Rk * Rk * (1.0f + 4.0e-6f);
-        float s = -inf;  // origin inside (or not clearly outside) the inflated sphere: never clear
-        if (lim > 0.0f && lim < inf) s = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
-        e.a = make_float4(mx, my, mz, s);
-        e.b.w = 0.0f;
+        float sv = -inf;  // origin inside (or not clearly outside) the inflated sphere: never clear
+        if (lim > 0.0f && lim < inf) sv = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
+        cone[slot] = make_float4(mx, my, mz, sv);
     } else {
         const float hx = fmax_(rec.p[3], 0.0f), hy = fmax_(rec.p[4], 0.0f), hz = fmax_(rec.p[5], 0.0f);
         finite = finite && hx < inf && hy < inf && hz < inf;
-        const float rho = hx + hy + hz;
-        const float M = cull_margin(cx, cy, cz, rho, ro, min_dist);
-        e.a = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
-        e.b = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 1.0f);
+        const float M = cull_margin(cx, cy, cz, hx + hy + hz, ro, min_dist);
+        slab[2u * slot] = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
+        slab[2u * slot + 1u] = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 0.0f);
     }
-    if (!finite) e.b.w = 3.0f;
-    return e;
+    if (!finite) *veto = 1u;
 }
 
 // true iff the half-line o + t d (t >= 0) provably stays clear of every primitive's margin zone.
-RM_DEV bool ray_misses_scene_v5(const CullEntry* tab, uint32_t n, float dx, float dy, float dz) {
+RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float dz) {
+    bool clear = *T.veto == 0u;  // no primitives (empty scene): every ray misses (wgsl:189-191)
+    for (uint32_t k = 0; k < T.n_cone; k++) {
+        const float4 a = T.cone[k];  // wave-uniform address: LDS broadcast
+        const float t = __builtin_fmaf(a.z, dz, __builtin_fmaf(a.y, dy, __builtin_fmaf(a.x, dx, -a.w)));
+        clear = clear && (t < 0.0f);  // NaN -> not clear
+        if ((k & 3u) == 3u && __ballot(clear) == 0ull) return false;
+    }
+    if (T.n_slab == 0u || __ballot(clear) == 0ull) return clear;
     // 1/d with |d_i| clamped away from 0 so that no 0 * inf = NaN can appear in the slab test
     const float tiny = 1.0e-30f;
     const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dx), tiny), dx));
     const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dy), tiny), dy));
     const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dz), tiny), dz));
-    bool clear = true;  // n == 0 (empty scene): every ray misses (wgsl:189-191)
-    for (uint32_t k = 0; k < n; k++) {
-        const float4 a = tab[k].a, b = tab[k].b;  // wave-uniform address: LDS broadcast
-        const uint32_t tag = __builtin_amdgcn_readfirstlane((uint32_t)b.w);
-        if (tag == 0u) {
-            const float t = __builtin_fmaf(a.z, dz, __builtin_fmaf(a.y, dy, __builtin_fmaf(a.x, dx, -a.w)));
-            clear = clear && (t < 0.0f);  // NaN -> not clear
-        } else if (tag == 1u) {
-            const float x1 = a.x * ix, x2 = b.x * ix, y1 = a.y * iy, y2 = b.y * iy, z1 = a.z * iz, z2 = b.z * iz;
-            const float tn = fmax_(fmin_(x1, x2), fmax_(fmin_(y1, y2), fmin_(z1, z2)));
-            const float tf = fmin_(fmax_(x1, x2), fmin_(fmax_(y1, y2), fmax_(z1, z2)));
-            const bool hits_box = tf >= fmax_(tn, 0.0f);  // a dropped NaN only widens the interval
-            clear = clear && !hits_box;
-        } else if (tag == 3u) {
-            clear = false;
-        }
-        if (__ballot(clear) == 0ull) break;
+    for (uint32_t k = 0; k < T.n_slab; k++) {
+        const float4 a = T.slab[2u * k], b = T.slab[2u * k + 1u];
+        const float x1 = a.x * ix, x2 = b.x * ix, y1 = a.y * iy, y2 = b.y * iy, z1 = a.z * iz, z2 = b.z * iz;
+        const float tn = fmax_(fmin_(x1, x2), fmax_(fmin_(y1, y2), fmin_(z1, z2)));
+        const float tf = fmin_(fmax_(x1, x2), fmin_(fmax_(y1, y2), fmax_(z1, z2)));
+        clear = clear && !(tf >= fmax_(tn, 0.0f));  // a dropped NaN only widens the interval
+        if ((k & 1u) == 1u && __ballot(clear) == 0ull) return false;
     }
     return clear;
 }
@@ -134,10 +132,13 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     float* sq_v = reinterpret_cast<float*>(sq_rid + V5_SQ);            // [6][V5_SQ]
     uint32_t* after = smem + POOL + WPT * (4u * V5_RQ + 7u * V5_SQ);
     float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
-    CullEntry* cullt = reinterpret_cast<CullEntry*>(after + WPT * L.spill_depth * 64u);    // [n_cull]
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(cullt + L.n_cull);
+    float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
+    float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(t_slab + 2u * L.n_slab);
     uint32_t* s_next = lprog + (PROG_IN_LDS ? L.n_rec * 8u : 0u);      // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
+    uint32_t* s_veto = s_next + 2;
+    const CullTables cullt{t_cone, t_slab, s_veto, L.n_cone, L.n_slab};
 
     rm_uniforms u = L.u;
     if (L.frames) u = L.frames[blockIdx.z];  // wave-uniform
@@ -153,7 +154,10 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
         for (uint32_t k = tid; k < L.n_rec * 8u; k += 64u * WPT) lprog[k] = src[k];
     }
-    for (uint32_t k = tid; k < L.n_cull; k += 64u * WPT) cullt[k] = cull_entry_v5(L.prog[k], ro, L.min_dist);
+    if (tid == 0u) *s_veto = 0u;
+    __syncthreads();
+    if (L.flags & 1u)
+        for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, t_cone, t_slab, s_veto);
 
     Prog prog;
     if constexpr (PROG_IN_LDS) prog.base = lprog;
@@ -218,7 +222,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
                 float gx, gy, gz;
                 gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
                 const bool culled = L.max_iter == 0u ||
-                                    ((L.flags & 1u) && ray_misses_scene_v5(cullt, L.n_cull, gx, gy, gz));
+                                    ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
                 if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                 const unsigned long long keep = __ballot(!culled);
                 if (!culled) {
@@ -362,56 +366,85 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pre-pass, one wave per tile, lane = pixel.  Walks the 16 AA samples in reference order and
-// stops at the first sample with a ray that cannot be culled: that tile goes on the work list
-// (cost = how many of that sample's 64 rays survive).  If ALL 1024 rays are provably misses the
-// tile is finished here: every lane has summed its pixel's 16 gamma-corrected floor colours in
-// the reference's order (wgsl:44-45, 68-69, 73-75), writes the pixel and reports cost 0.
+// Pre-pass, one workgroup per tile.  Runs the miss test on the tile's AA samples and stops as soon
+// as one ray cannot be culled: that tile goes on the work list (cost = how many of that sample's
+// 64 rays survive).  If ALL 1024 rays are provable misses the tile is finished here: the 16
+// gamma-corrected floor colours of each pixel are summed in the reference's order (wgsl:44-45,
+// 68-69, 73-75), the pixel is written and the tile reports cost 0.
 // ~60 % of the tiles of the metric frame end this way and never occupy a marching workgroup.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost) {
+#ifndef RM_V5_PRE_TILES
+#define RM_V5_PRE_TILES 1
+#endif
+constexpr uint32_t V5_PRE_TILES = RM_V5_PRE_TILES;  // tiles per pre-pass workgroup
+
+__global__ __launch_bounds__(256) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost, uint32_t n_tiles) {
+    // 4 waves per tile: wave w tests AA samples w, w+4, w+8, w+12 (lane = pixel) and parks each
+    // sample's floor colour code in LDS; thread t < 64 then sums pixel t's 16 samples in order.
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    CullEntry* cullt = reinterpret_cast<CullEntry*>(smem);
-    const uint32_t lane = threadIdx.x;
+    float* codes = reinterpret_cast<float*>(smem);                  // [16][64] miss codes (see miss_code)
+    uint32_t* s_surv = smem + 1024u;                                // survivors found by any wave
+    uint32_t* s_veto = smem + 1025u;
+    float4* t_cone = reinterpret_cast<float4*>(smem + 1024u + 4u);
+    float4* t_slab = t_cone + L.n_cone;
+    const CullTables cullt{t_cone, t_slab, s_veto, L.n_cone, L.n_slab};
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     rm_uniforms u = L.u;
     if (L.frames) u = L.frames[blockIdx.z];
     float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
-    for (uint32_t k = lane; k < L.n_cull; k += 64u) cullt[k] = cull_entry_v5(L.prog[k], ro, L.min_dist);
+    if (tid == 0u) *s_veto = 0u;
     __syncthreads();
+    if (L.flags & 1u)
+        for (uint32_t k = tid; k < L.n_rec; k += 256u) cull_build_v5(L.prog[k], ro, L.min_dist, t_cone, t_slab, s_veto);
     const uint32_t tiles_x = (L.W + 7u) / 8u;
-    const uint32_t tile_x = blockIdx.x % tiles_x, tile_y = blockIdx.x / tiles_x;
+  for (uint32_t tile = blockIdx.x * V5_PRE_TILES; tile < n_tiles && tile < (blockIdx.x + 1u) * V5_PRE_TILES; tile++) {
+    if (tid == 0u) *s_surv = 0u;
+    __syncthreads();
+    const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
     const uint32_t px = tx < L.W ? tx : L.W - 1u, ry = ty < L.rows ? ty : L.rows - 1u;
     const float sx = screen_x(px, L.W), sy = screen_y(rm_global_row(L, ry), L.H);
     const bool may_cull = (L.flags & 1u) != 0u || L.max_iter == 0u;
-    uint32_t survivors = 64u;
-    float tr = 0.0f, tg = 0.0f, tb = 0.0f;
-    if (may_cull) {
-        survivors = 0u;
-        for (uint32_t s = 0; s < 16u; s++) {
+    if (!may_cull) {
+        if (tid == 0u) *s_surv = 64u;
+    } else {
+        for (uint32_t s = wave; s < 16u; s += 4u) {
+            if (*reinterpret_cast<volatile uint32_t*>(s_surv) != 0u) break;  // another wave found a live ray
             float dx, dy, dz;
             gen_ray(u, ro, sx, sy, s >> 2, s & 3u, dx, dy, dz);
-            const bool culled = L.max_iter == 0u || ray_misses_scene_v5(cullt, L.n_cull, dx, dy, dz);
-            survivors = (uint32_t)__popcll(__ballot(!culled));
-            if (survivors != 0u) break;
-            const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
+            const bool culled = L.max_iter == 0u || ((L.flags & 1u) && ray_misses_scene_v5(cullt, dx, dy, dz));
+            const uint32_t survivors = (uint32_t)__popcll(__ballot(!culled));
+            if (survivors != 0u) {
+                if (lane == 0u) atomicMax(s_surv, survivors);
+                break;
+            }
+            codes[s * 64u + lane] = miss_code(ro, dx, dy, dz);  // wgsl:117-130
+        }
+    }
+    __syncthreads();
+    const uint32_t survivors = *s_surv;
+    if (survivors == 0u && tid < 64u && tx < L.W && ty < L.rows) {
+        float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+#pragma unroll 4
+        for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
+            const float code = codes[s * 64u + lane];
             float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-            if (c >= 0) {
-                const float g = 0.2f * (float)c;
+            if (code > -2.5f) {  // floor (wgsl:127); -3 = black
+                const float g = 0.2f * (-1.0f - code);
                 cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
             }
             tr += __builtin_sqrtf(cr);
             tg += __builtin_sqrtf(cg);
             tb += __builtin_sqrtf(cb);
         }
-    }
-    if (survivors == 0u && tx < L.W && ty < L.rows) {
         float4 o;
-        o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;
+        o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
         reinterpret_cast<float4*>(out)[(size_t)ty * L.W + tx] = o;
     }
-    if (lane == 0u) cost[(size_t)blockIdx.z * gridDim.x + blockIdx.x] = survivors;  // 0 = done, else 1..64
+    if (tid == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = survivors;  // 0 = done, else 1..64
+    __syncthreads();  // codes[] and *s_surv are reused by the next tile
+  }
 }
 
 // Work list of one frame (blockIdx.x = frame): ids of the tiles with cost > 0, by descending cost
