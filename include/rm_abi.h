@@ -82,7 +82,8 @@ enum rm_status {
 /* rm_set_option / rm_get_info keys */
 enum rm_option {
     RM_OPT_KERNEL = 0,     /* which kernel rm_draw launches; see enum rm_kernel */
-    RM_OPT_TIMING = 1,     /* 1: bracket every kernel launch with HIP events (rm_get_info RM_INFO_KERNEL_MS) */
+    RM_OPT_TIMING = 1,     /* 1: bracket every launch of the dominant (march) kernel with HIP events on its stream,
+                              without synchronising; read with rm_get_info(RM_INFO_KERNEL_MS) */
     RM_OPT_STRICT_CAP = 2, /* reserved */
     RM_OPT_REFILL_MIN = 3, /* raypool kernels: parked lanes that trigger a refill, 1..64 (default 8) */
     RM_OPT_CULL = 4,       /* v3 kernels: 1 (default) = shade rays that provably miss the scene without marching */
@@ -105,7 +106,8 @@ enum rm_kernel {
     RM_KERNEL_V5 = 12, RM_KERNEL_V5_LDS = 13
 };
 enum rm_info {
-    RM_INFO_KERNEL_MS = 0,       /* duration of the last timed kernel launch, milliseconds */
+    RM_INFO_KERNEL_MS = 0,       /* mean duration (ms) of the march kernel over the launches timed since the last query
+                                    (synchronises on them and resets the set) */
     RM_INFO_PROGRAM_COMMANDS = 1,
     RM_INFO_PROGRAM_WORDS = 2,
     RM_INFO_PROGRAM_DEPTH = 3,   /* maximum value-stack depth of the current program */

@@ -37,6 +37,10 @@ struct rm_ctx {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // RM_OPT_TIMING: one event pair per timed launch of the dominant kernel, read back (and
+    // reset) by rm_get_info(RM_INFO_KERNEL_MS): no synchronisation inside the launch path.
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
+    size_t tev_used = 0;
     // host shadows of the three buffers of the reference's bind group
     rm_limits limits{0.01f, 100.0f, 100u};  // renderer.rs:133-137
     rm_uniforms uniforms{};                 // Uniforms::default(), renderer.rs:126
@@ -129,6 +133,8 @@ int ensure_program(rm_ctx* c) {
 }
 
 int finish_launch(rm_ctx* c, hipStream_t s);
+int time_begin(rm_ctx* c, hipStream_t s);
+int time_end(rm_ctx* c, hipStream_t s);
 
 template <int R, int WPT>
 int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
@@ -175,10 +181,12 @@ int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames,
         c->stats_valid_bytes = need;
         L.stats = c->d_stats;
     }
+    if (int rc = time_begin(c, s)) return rc;
     if (lds)
         hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgLds, true, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
     else
         hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgSmem, false, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
+    if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
 }
 
@@ -251,10 +259,12 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         c->stats_valid_bytes = sneed;
         L.stats = c->d_stats;
     }
+    if (int rc = time_begin(c, s)) return rc;
     if (lds)
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     else
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
 }
 
@@ -281,10 +291,12 @@ int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, h
     size_t shmem = (size_t)(1024u + 4u * rmk::QCAP + 7u * rmk::QCAP) * 4u + (size_t)L.spill_depth * 64u * 4u +
                    (size_t)L.n_cull * 16u + (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per wave", shmem);
+    if (int rc = time_begin(c, s)) return rc;
     if (lds)
         hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgLds, true>), grid, dim3(64), shmem, s, L);
     else
         hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgSmem, false>), grid, dim3(64), shmem, s, L);
+    if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
 }
 
@@ -310,8 +322,9 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.order = nullptr;
     L.stats = nullptr;
     L.u = c->uniforms;
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev0, s));
     int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_V5_LDS : c->kernel;
+    if (kernel == RM_KERNEL_RAYPOOL || kernel == RM_KERNEL_RAYPOOL_LDS || kernel == RM_KERNEL_PIXEL)
+        if (int rc = time_begin(c, s)) return rc;
     switch (kernel) {
     case RM_KERNEL_RAYPOOL:
     case RM_KERNEL_RAYPOOL_LDS: {
@@ -338,18 +351,31 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     default:
         return fail(c, RM_ERR_ARG, "kernel variant %d is not available", kernel);
     }
+    if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
+}
+
+int time_begin(rm_ctx* c, hipStream_t s) {
+    if (!c->timing) return RM_OK;
+    if (c->tev_used == c->tev.size()) {
+        if (c->tev.size() >= 4096) return RM_OK;  // stop recording, keep running
+        hipEvent_t a, b;
+        HIP_TRY(c, hipEventCreate(&a));
+        HIP_TRY(c, hipEventCreate(&b));
+        c->tev.emplace_back(a, b);
+    }
+    HIP_TRY(c, hipEventRecord(c->tev[c->tev_used].first, s));
+    return RM_OK;
+}
+int time_end(rm_ctx* c, hipStream_t s) {
+    if (!c->timing || c->tev_used >= c->tev.size()) return RM_OK;
+    HIP_TRY(c, hipEventRecord(c->tev[c->tev_used].second, s));
+    c->tev_used++;
+    return RM_OK;
 }
 
 int finish_launch(rm_ctx* c, hipStream_t s) {
     HIP_TRY(c, hipGetLastError());
-    if (c->timing) {
-        HIP_TRY(c, hipEventRecord(c->ev1, s));
-        HIP_TRY(c, hipEventSynchronize(c->ev1));
-        float ms = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->last_kernel_ms = ms;
-    }
     return RM_OK;
 }
 
@@ -427,6 +453,7 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_cost) (void)hipFree(c->d_cost);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    for (auto& e : c->tev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -621,7 +648,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
         if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_V5_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
         c->kernel = (int)value;
         return RM_OK;
-    case RM_OPT_TIMING: c->timing = value != 0; return RM_OK;
+    case RM_OPT_TIMING: c->timing = value != 0; c->tev_used = 0; return RM_OK;
     case RM_OPT_STRICT_CAP: return RM_OK;
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
     case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
@@ -643,7 +670,19 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     if (!c) return RM_ERR_NULL;
     if (!out) return fail(c, RM_ERR_NULL, "rm_get_info: out is NULL");
     switch (key) {
-    case RM_INFO_KERNEL_MS: *out = c->last_kernel_ms; return RM_OK;
+    case RM_INFO_KERNEL_MS: {  // mean duration of the dominant kernel over the launches timed since the last query
+        double sum = 0.0;
+        for (size_t i = 0; i < c->tev_used; i++) {
+            HIP_TRY(c, hipEventSynchronize(c->tev[i].second));
+            float ms = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&ms, c->tev[i].first, c->tev[i].second));
+            sum += ms;
+        }
+        if (c->tev_used) c->last_kernel_ms = sum / (double)c->tev_used;
+        c->tev_used = 0;
+        *out = c->last_kernel_ms;
+        return RM_OK;
+    }
     case RM_INFO_DEVICE: *out = c->device; return RM_OK;
     case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
     case RM_INFO_PROGRAM_COMMANDS:

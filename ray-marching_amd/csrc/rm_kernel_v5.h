@@ -28,7 +28,7 @@
 
 namespace rmk {
 
-constexpr uint32_t V5_RQ = 128u;  // ready ring entries per wave (a produce round adds <= 64 to < 64)
+constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
 constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
 
 // Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     // lane state: evaluation point = b + d * sc
     float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t it = 0u, rid = 0u, mode = M_EMPTY;
-    uint32_t rq_head = 0u, rq_tail = 0u, sq_n = 0u;  // wave-uniform ring cursors
+    uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u;  // wave-uniform cursors of the ready / shade buffers
     bool pool_open = true;                           // wave-uniform: the shared pool may still hold rays
 
     auto flush_shade = [&]() {  // shade every waiting entry (<= 64): one lane per entry
@@ -207,49 +207,56 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     };
 
     for (;;) {
-        // ---- A. idle lanes take ready rays; the ring is topped up 64 candidates at a time ----
-        const unsigned long long want = __ballot(mode == M_EMPTY);
+        // ---- A. idle lanes take ready rays; when the buffer is empty it is refilled with the
+        //         survivors of the next 64 candidates of the pool ----
+        const unsigned long long want0 = __ballot(mode == M_EMPTY);
         const unsigned long long live0 = __ballot(mode < M_DONE_HIT);
-        const uint32_t n_want = (uint32_t)__popcll(want);
-        if (n_want != 0u && (live0 == 0ull || n_want >= refill_min)) {
-            while (rq_tail - rq_head < n_want && pool_open) {
-                uint32_t base = 0u;
-                if (lane == 0u) base = atomicAdd(s_next, 64u);
-                base = __builtin_amdgcn_readfirstlane(base);
-                if (base >= POOL) { pool_open = false; break; }
-                n_prod++;
-                const uint32_t r = base + lane, s = base >> 6;
-                float gx, gy, gz;
-                gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
-                const bool culled = L.max_iter == 0u ||
-                                    ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
-                if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
-                const unsigned long long keep = __ballot(!culled);
-                if (!culled) {
-                    const uint32_t e = (rq_tail + lane_rank(keep)) & (V5_RQ - 1u);
-                    rq_rid[e] = r;
-                    rq_d[e] = gx; rq_d[V5_RQ + e] = gy; rq_d[2u * V5_RQ + e] = gz;
+        if (want0 != 0ull && (live0 == 0ull || (uint32_t)__popcll(want0) >= refill_min)) {
+            unsigned long long want = want0;
+            while (want != 0ull) {
+                if (rq_pos == rq_cnt) {  // buffer empty: produce
+                    if (!pool_open) {
+                        if (mode == M_EMPTY) mode = M_RETIRED;  // pool exhausted and buffer drained
+                        break;
+                    }
+                    uint32_t base = 0u;
+                    if (lane == 0u) base = atomicAdd(s_next, 64u);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (base >= POOL) { pool_open = false; continue; }
+                    n_prod++;
+                    const uint32_t r = base + lane, s = base >> 6;
+                    float gx, gy, gz;
+                    gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
+                    const bool culled = L.max_iter == 0u || ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+                    if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
+                    const unsigned long long keep = __ballot(!culled);
+                    if (!culled) {
+                        const uint32_t e = lane_rank(keep);
+                        rq_rid[e] = r;
+                        rq_d[e] = gx; rq_d[V5_RQ + e] = gy; rq_d[2u * V5_RQ + e] = gz;
+                    }
+                    rq_pos = 0u;
+                    rq_cnt = (uint32_t)__popcll(keep);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    continue;
                 }
-                rq_tail += (uint32_t)__popcll(keep);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            const uint32_t avail = rq_tail - rq_head;
-            if (mode == M_EMPTY) {
-                const uint32_t rank = lane_rank(want);
-                if (rank < avail) {
-                    const uint32_t e = (rq_head + rank) & (V5_RQ - 1u);
-                    rid = rq_rid[e];
-                    dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
-                    bx = ro.x; by = ro.y; bz = ro.z;
-                    sc = 0.0f;  // dist (wgsl:88)
-                    it = 0u;
-                    mode = M_MARCH;
-                } else if (!pool_open) {
-                    mode = M_RETIRED;  // pool exhausted and ring drained
+                const uint32_t avail = rq_cnt - rq_pos, n_want = (uint32_t)__popcll(want);
+                if (mode == M_EMPTY) {
+                    const uint32_t rank = lane_rank(want);
+                    if (rank < avail) {
+                        const uint32_t e = rq_pos + rank;
+                        rid = rq_rid[e];
+                        dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
+                        bx = ro.x; by = ro.y; bz = ro.z;
+                        sc = 0.0f;  // dist (wgsl:88)
+                        it = 0u;
+                        mode = M_MARCH;
+                    }
                 }
+                rq_pos += n_want < avail ? n_want : avail;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                want = __ballot(mode == M_EMPTY);
             }
-            rq_head += n_want < avail ? n_want : avail;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         const unsigned long long live = __ballot(mode < M_DONE_HIT);
         if (live == 0ull) {
