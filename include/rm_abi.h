@@ -57,6 +57,12 @@ typedef struct rm_limits {
     uint32_t max_iter;
 } rm_limits;
 
+/* Command stream (csg/builder.rs:1-62): u32 opcode followed by f32::to_bits parameters, post-order.
+ *   reference:  Sphere 0 (c.xyz, r)   Box 1 (c.xyz, half-extents.xyz)   Union 100   Subtraction 101
+ *   extensions (NOT implemented by the reference, semantics in DESIGN.md section 8; only the v5 kernels):
+ *               Plane 2 (n.xyz, h)   Cylinder 10 (c.xyz, r, half_h)   Intersection 102   SmoothUnion 110 (k)
+ * Any other opcode is rejected with RM_ERR_OPCODE. */
+
 /* binding numbers of the reference's bind group (renderer.rs:60-94, 149-166) */
 enum rm_buffer {
     RM_BUF_LIMITS = 0,   /* 12 B,  initial {0.01, 100.0, 100}      renderer.rs:130-140 */

@@ -29,9 +29,14 @@ rmh_node* rmh_sphere(const float center[3], float radius);
 rmh_node* rmh_box(const float center[3], const float radius[3]);
 rmh_node* rmh_union(const rmh_node* lhs, const rmh_node* rhs);
 rmh_node* rmh_subtraction(const rmh_node* lhs, const rmh_node* rhs);
+/* extension node types (not implemented by the reference; DESIGN.md "Extension node types") */
+rmh_node* rmh_plane(const float normal[3], float h);
+rmh_node* rmh_cylinder(const float center[3], float radius, float half_height);
+rmh_node* rmh_intersection(const rmh_node* lhs, const rmh_node* rhs);
+rmh_node* rmh_smooth_union(const rmh_node* lhs, const rmh_node* rhs, float k);
 rmh_node* rmh_node_clone(const rmh_node* n);
 void rmh_node_free(rmh_node* n);
-/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced); NULL if unknown. */
+/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced; with extension nodes: g8x, g32s, ext_mix); NULL if unknown. */
 rmh_node* rmh_scene(const char* name);
 
 /* ---- CSGCommandBufferBuilder */

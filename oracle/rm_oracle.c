@@ -70,6 +70,15 @@ enum {
 #define RMO_CMD_BOX 1u
 #define RMO_CMD_UNION 100u
 #define RMO_CMD_SUBTRACTION 101u
+/* ---- extensions (NOT implemented by the reference; semantics defined by this repo, DESIGN.md
+ * "Extension node types"; parity with the reference is undefined for them) ------------------
+ * Plane = 2 and Intersection = 102 are the slots the reference reserves by comment
+ * (builder.rs:8,14; csg/mod.rs:34,39).  Cylinder and SmoothUnion (BASELINE.json configs 2-3)
+ * take numbers outside every reserved slot (2, 102, 200-205). */
+#define RMO_CMD_PLANE 2u          /* normal vec3, h f32:            dot(p, n) + h                  */
+#define RMO_CMD_CYLINDER 10u      /* center vec3, radius, half_h:   capped cylinder along y         */
+#define RMO_CMD_INTERSECTION 102u /*                                max(a, b)                       */
+#define RMO_CMD_SMOOTH_UNION 110u /* k f32:                         polynomial smooth minimum       */
 
 /* ---- scalar helpers --------------------------------------------------------------- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -138,8 +147,20 @@ RMO_API int rmo_validate_program(uint32_t cmd_count, const uint32_t* words, uint
         case RMO_CMD_BOX:
             if (ptr + 6 > n_words) return RMO_ERR_TRUNCATED;
             ptr += 6; depth++; break;
+        case RMO_CMD_PLANE:
+            if (ptr + 4 > n_words) return RMO_ERR_TRUNCATED;
+            ptr += 4; depth++; break;
+        case RMO_CMD_CYLINDER:
+            if (ptr + 5 > n_words) return RMO_ERR_TRUNCATED;
+            ptr += 5; depth++; break;
+        case RMO_CMD_SMOOTH_UNION:
+            if (ptr + 1 > n_words) return RMO_ERR_TRUNCATED;
+            ptr += 1;
+            if (depth < 2) return RMO_ERR_UNDERFLOW;
+            depth--; break;
         case RMO_CMD_UNION:
         case RMO_CMD_SUBTRACTION:
+        case RMO_CMD_INTERSECTION:
             if (depth < 2) return RMO_ERR_UNDERFLOW;
             depth--; break;
         default:
@@ -179,6 +200,38 @@ static float map_scene(const rmo_scene* sc, v3 pos) {
             v3 q = { fabsf(pos.x - c.x) - r.x, fabsf(pos.y - c.y) - r.y, fabsf(pos.z - c.z) - r.z };
             v3 qp = { rmo_max(q.x, 0.0f), rmo_max(q.y, 0.0f), rmo_max(q.z, 0.0f) };
             val = length3(qp) + rmo_min(rmo_max(q.x, rmo_max(q.y, q.z)), 0.0f);
+        } break;
+        case RMO_CMD_PLANE: { /* extension: dot(pos, n) + h */
+            v3 n = { u2f(w[ptr]), u2f(w[ptr + 1]), u2f(w[ptr + 2]) };
+            float h = u2f(w[ptr + 3]);
+            ptr += 4;
+            val = dot3(pos, n) + h;
+        } break;
+        case RMO_CMD_CYLINDER: { /* extension: capped cylinder along y (exact SDF) */
+            v3 c = { u2f(w[ptr]), u2f(w[ptr + 1]), u2f(w[ptr + 2]) };
+            float r = u2f(w[ptr + 3]), hh = u2f(w[ptr + 4]);
+            ptr += 5;
+            float dx = pos.x - c.x, dz = pos.z - c.z;
+            float qx = sqrtf(dx * dx + dz * dz) - r;
+            float qy = fabsf(pos.y - c.y) - hh;
+            float mx = rmo_max(qx, 0.0f), my = rmo_max(qy, 0.0f);
+            val = rmo_min(rmo_max(qx, qy), 0.0f) + sqrtf(mx * mx + my * my);
+        } break;
+        case RMO_CMD_INTERSECTION: { /* extension */
+            float b = stack[--size];
+            float a = stack[--size];
+            val = rmo_max(a, b);
+        } break;
+        case RMO_CMD_SMOOTH_UNION: { /* extension: min(a,b) - h*h*k/4, h = max(k-|a-b|,0)/k; k <= 0: plain min */
+            float k = u2f(w[ptr]);
+            ptr += 1;
+            float b = stack[--size];
+            float a = stack[--size];
+            val = rmo_min(a, b);
+            if (k > 0.0f) {
+                float h = rmo_max(k - fabsf(a - b), 0.0f) / k;
+                val = val - ((h * h) * k) * 0.25f;
+            }
         } break;
         case RMO_CMD_UNION: { /* wgsl:242-246 */
             float b = stack[--size];
@@ -448,6 +501,23 @@ RMO_API void rmo_build_commands(const rmo_node* nodes, int32_t root, rmo_builder
         rmo_builder_push_command(b, RMO_CMD_BOX);
         rmo_builder_push_param_vec3(b, n->p);
         rmo_builder_push_param_vec3(b, n->p + 3);
+        break;
+    case RMO_CMD_PLANE: /* extension */
+        rmo_builder_push_command(b, RMO_CMD_PLANE);
+        rmo_builder_push_param_vec3(b, n->p);
+        rmo_builder_push_param_float(b, n->p[3]);
+        break;
+    case RMO_CMD_CYLINDER: /* extension */
+        rmo_builder_push_command(b, RMO_CMD_CYLINDER);
+        rmo_builder_push_param_vec3(b, n->p);
+        rmo_builder_push_param_float(b, n->p[3]);
+        rmo_builder_push_param_float(b, n->p[4]);
+        break;
+    case RMO_CMD_SMOOTH_UNION: /* extension: lhs, rhs, operator, k */
+        rmo_build_commands(nodes, n->lhs, b);
+        rmo_build_commands(nodes, n->rhs, b);
+        rmo_builder_push_command(b, RMO_CMD_SMOOTH_UNION);
+        rmo_builder_push_param_float(b, n->p[0]);
         break;
     default: /* operations/mod.rs:13-17: lhs, rhs, then the operator */
         rmo_build_commands(nodes, n->lhs, b);

@@ -14,6 +14,7 @@ import numpy as np
 
 F = np.float32
 CMD_SPHERE, CMD_BOX, CMD_UNION, CMD_SUBTRACTION = 0, 1, 100, 101
+CMD_PLANE, CMD_CYLINDER, CMD_INTERSECTION, CMD_SMOOTH_UNION = 2, 10, 102, 110   # extensions (not in the reference)
 
 
 def _f(x):
@@ -80,6 +81,27 @@ def map_scene(cmd_count, words, max_dist, px, py, pz):
             outside = np.sqrt((mx * mx + my * my) + mz * mz)
             inside = fmin(fmax(qx, fmax(qy, qz)), F(0))
             val = outside + inside
+        elif op == CMD_PLANE:
+            nx, ny, nz, h = (_wf(words, ptr + k) for k in range(4)); ptr += 4
+            val = ((px * nx + py * ny) + pz * nz) + h
+        elif op == CMD_CYLINDER:
+            cx, cy, cz, r, hh = (_wf(words, ptr + k) for k in range(5)); ptr += 5
+            dx, dz = px - cx, pz - cz
+            qx = np.sqrt(dx * dx + dz * dz) - r
+            qy = np.abs(py - cy) - hh
+            mx, my = fmax(qx, F(0)), fmax(qy, F(0))
+            val = fmin(fmax(qx, qy), F(0)) + np.sqrt(mx * mx + my * my)
+        elif op == CMD_INTERSECTION:
+            b = stack.pop(); a = stack.pop()
+            val = fmax(a, b)
+        elif op == CMD_SMOOTH_UNION:
+            k = _wf(words, ptr); ptr += 1
+            b = stack.pop(); a = stack.pop()
+            val = fmin(a, b)
+            if k > 0:
+                with np.errstate(invalid="ignore"):
+                    h = fmax(k - np.abs(a - b), F(0)) / k
+                val = val - ((h * h) * k) * F(0.25)
         elif op == CMD_UNION:
             b = stack.pop(); a = stack.pop()
             val = fmin(a, b)

@@ -141,10 +141,14 @@ def host_lib():
         L.rmh_box.argtypes = [f32p, f32p]
         L.rmh_union.argtypes = [vp, vp]
         L.rmh_subtraction.argtypes = [vp, vp]
+        L.rmh_plane.argtypes = [f32p, C.c_float]
+        L.rmh_cylinder.argtypes = [f32p, C.c_float, C.c_float]
+        L.rmh_intersection.argtypes = [vp, vp]
+        L.rmh_smooth_union.argtypes = [vp, vp, C.c_float]
         L.rmh_node_clone.argtypes = [vp]
         L.rmh_scene.argtypes = [C.c_char_p]
         for n in ("rmh_sphere", "rmh_box", "rmh_union", "rmh_subtraction", "rmh_node_clone", "rmh_scene",
-                  "rmh_builder_new"):
+                  "rmh_builder_new", "rmh_plane", "rmh_cylinder", "rmh_intersection", "rmh_smooth_union"):
             getattr(L, n).restype = vp
         L.rmh_node_free.argtypes = [vp]
         L.rmh_node_free.restype = None

@@ -15,6 +15,11 @@ class CSGCommandType(enum.IntEnum):  # builder.rs:3-24
     Box = 1
     Union = 100
     Subtraction = 101
+    # extensions (not implemented by the reference)
+    Plane = 2
+    Cylinder = 10
+    Intersection = 102
+    SmoothUnion = 110
 
 
 def _f3(v):
@@ -91,6 +96,23 @@ def Union(lhs, rhs):  # operations/mod.rs:55
 
 def Subtraction(lhs, rhs):  # operations/mod.rs:56
     return CSGNode(_ffi.host_lib().rmh_subtraction(lhs._h, rhs._h))
+
+
+# ---- extension node types (no counterpart in the reference; DESIGN.md "Extension node types") ----
+def Plane(normal=(0.0, 1.0, 0.0), h=0.0):
+    return CSGNode(_ffi.host_lib().rmh_plane(_f3(normal), float(h)))
+
+
+def Cylinder(center=(0.0, 0.0, 0.0), radius=1.0, half_height=1.0):
+    return CSGNode(_ffi.host_lib().rmh_cylinder(_f3(center), float(radius), float(half_height)))
+
+
+def Intersection(lhs, rhs):
+    return CSGNode(_ffi.host_lib().rmh_intersection(lhs._h, rhs._h))
+
+
+def SmoothUnion(lhs, rhs, k=0.25):
+    return CSGNode(_ffi.host_lib().rmh_smooth_union(lhs._h, rhs._h, float(k)))
 
 
 def scene(name):

@@ -19,10 +19,14 @@ namespace ray_marching::csg {
 enum class CSGCommandType : uint32_t {  // builder.rs:3-24
     Sphere = 0,
     Box = 1,
-    // Plane (reserved by comment in the reference)
     Union = 100,
     Subtraction = 101,
-    // Intersection; 200.. TranslationPush/Pop, RotationPush/Pop, ScalePush/Pop (reserved)
+    // 200.. TranslationPush/Pop, RotationPush/Pop, ScalePush/Pop: reserved by comment in the reference, not built.
+    // ---- extensions: NOT implemented by the reference (DESIGN.md "Extension node types") ----
+    Plane = 2,           // slot the reference reserves by comment (builder.rs:8)
+    Cylinder = 10,       // BASELINE.json config 2
+    Intersection = 102,  // slot the reference reserves by comment (builder.rs:14)
+    SmoothUnion = 110,   // BASELINE.json config 3
 };
 
 struct CSGCommandBufferBuilder {  // builder.rs:26-62
@@ -85,6 +89,23 @@ struct Box {  // box.rs:8-12 ("radius" = half extents)
     }
 };
 
+// ---- extension primitives (no counterpart in the reference) ----
+struct Plane {  // dot(p, normal) + h; the normal is used as given
+    std::array<float, 3> normal{0, 1, 0};
+    float h = 0.0f;
+    void build_commands(CSGCommandBufferBuilder& builder) const {
+        builder.push_command(CSGCommandType::Plane).push_param_vec3(normal).push_param_float(h);
+    }
+};
+struct Cylinder {  // capped, along y
+    std::array<float, 3> center{0, 0, 0};
+    float radius = 1.0f;
+    float half_height = 1.0f;
+    void build_commands(CSGCommandBufferBuilder& builder) const {
+        builder.push_command(CSGCommandType::Cylinder).push_param_vec3(center).push_param_float(radius).push_param_float(half_height);
+    }
+};
+
 struct Union {  // operations/mod.rs:55 via impl_binary_operation!
     NodeBox lhs, rhs;
     void build_commands(CSGCommandBufferBuilder& builder) const;
@@ -94,13 +115,27 @@ struct Subtraction {  // operations/mod.rs:56
     void build_commands(CSGCommandBufferBuilder& builder) const;
 };
 
-class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands)
+struct Intersection {  // extension: max(a, b)
+    NodeBox lhs, rhs;
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+struct SmoothUnion {  // extension: polynomial smooth minimum with blend width k; the operator carries k as one parameter
+    NodeBox lhs, rhs;
+    float k = 0.25f;
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+
+class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands) + the extension node types
   public:
-    using Variant = std::variant<Sphere, Box, Union, Subtraction>;
+    using Variant = std::variant<Sphere, Box, Union, Subtraction, Plane, Cylinder, Intersection, SmoothUnion>;
     CSGNode(Sphere s) : v_(std::move(s)) {}
     CSGNode(Box b) : v_(std::move(b)) {}
     CSGNode(Union u) : v_(std::move(u)) {}
     CSGNode(Subtraction s) : v_(std::move(s)) {}
+    CSGNode(Plane p) : v_(std::move(p)) {}
+    CSGNode(Cylinder c) : v_(std::move(c)) {}
+    CSGNode(Intersection i) : v_(std::move(i)) {}
+    CSGNode(SmoothUnion s) : v_(std::move(s)) {}
     void build_commands(CSGCommandBufferBuilder& builder) const {
         std::visit([&](const auto& n) { n.build_commands(builder); }, v_);
     }
@@ -129,6 +164,23 @@ inline void Subtraction::build_commands(CSGCommandBufferBuilder& builder) const 
     lhs->build_commands(builder);
     rhs->build_commands(builder);
     builder.push_command(CSGCommandType::Subtraction);
+}
+
+inline void Intersection::build_commands(CSGCommandBufferBuilder& builder) const {
+    lhs->build_commands(builder);
+    rhs->build_commands(builder);
+    builder.push_command(CSGCommandType::Intersection);
+}
+inline void SmoothUnion::build_commands(CSGCommandBufferBuilder& builder) const {
+    lhs->build_commands(builder);
+    rhs->build_commands(builder);
+    builder.push_command(CSGCommandType::SmoothUnion).push_param_float(k);
+}
+inline CSGNode make_intersection(CSGNode a, CSGNode b) {
+    return CSGNode(Intersection{NodeBox(std::move(a)), NodeBox(std::move(b))});
+}
+inline CSGNode make_smooth_union(CSGNode a, CSGNode b, float k) {
+    return CSGNode(SmoothUnion{NodeBox(std::move(a)), NodeBox(std::move(b)), k});
 }
 
 inline CSGNode make_union(CSGNode a, CSGNode b) { return CSGNode(Union{NodeBox(std::move(a)), NodeBox(std::move(b))}); }

@@ -75,7 +75,36 @@ inline CSGNode g32() { return fold_left(grid_prims(4, 4, 0x5DF00020u)); }
 inline CSGNode g64() { return fold_left(grid_prims(8, 4, 0x5DF00040u)); }
 inline CSGNode g32_balanced() { return fold_balanced(grid_prims(4, 4, 0x5DF00020u)); }
 
+// ---- scenes using extension node types (BASELINE.json configs 2-3 as literally worded) ----
+inline CSGNode g8x() {  // sphere U box - cylinder (+ floor slab)
+    CSGNode s0(csg::Sphere{{0, 0, 0}, 1.0f});
+    CSGNode b1(csg::Box{{0, 0, 0}, {0.8f, 0.8f, 0.8f}});
+    CSGNode c2(csg::Cylinder{{0.9f, 0.5f, 0.6f}, 0.45f, 0.9f});
+    CSGNode b3(csg::Box{{0, -1.2f, 0}, {1.5f, 0.1f, 1.5f}});
+    return csg::make_union(csg::make_subtraction(csg::make_union(s0, b1), c2), b3);
+}
+inline CSGNode g32s() {  // G32 with Union -> SmoothUnion(k = 0.25)
+    std::vector<CSGNode> prims = grid_prims(4, 4, 0x5DF00020u);
+    CSGNode acc = prims[0];
+    for (size_t k = 0; k + 1 < prims.size(); k++)
+        acc = (k % 4 == 3) ? csg::make_subtraction(std::move(acc), prims[k + 1])
+                           : csg::make_smooth_union(std::move(acc), prims[k + 1], 0.25f);
+    return acc;
+}
+inline CSGNode ext_mix() {  // every extension node type in one tree
+    CSGNode a = csg::make_smooth_union(CSGNode(csg::Sphere{{-0.6f, 0, 0}, 0.7f}),
+                                       CSGNode(csg::Cylinder{{0.5f, 0.0f, 0.1f}, 0.4f, 0.8f}), 0.3f);
+    CSGNode b = csg::make_intersection(CSGNode(csg::Box{{0, 0, 0}, {1.4f, 0.9f, 1.0f}}),
+                                       CSGNode(csg::Plane{{0.0f, 1.0f, 0.2f}, 0.35f}));
+    CSGNode c = csg::make_smooth_union(std::move(a),
+                                       csg::make_subtraction(std::move(b), CSGNode(csg::Sphere{{0.2f, 0.3f, 0.9f}, 0.5f})), 0.15f);
+    return csg::make_union(std::move(c), CSGNode(csg::Cylinder{{-1.4f, -0.6f, -0.5f}, 0.25f, 0.5f}));
+}
+
 inline std::optional<CSGNode> by_name(const std::string& name) {
+    if (name == "g8x") return g8x();
+    if (name == "g32s") return g32s();
+    if (name == "ext_mix") return ext_mix();
     if (name == "g1") return g1();
     if (name == "g8") return g8();
     if (name == "g32") return g32();

@@ -140,10 +140,12 @@ template <int R, int WPT>
 int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
     using G = rmk::TileGeom<R>;
     RmLaunch L = L_in;
+    if (c->decoded.has_extensions)
+        return fail(c, RM_ERR_ARG, "the v3 kernels render reference node types only (program uses extension nodes)");
     // Miss-ray culling: one table entry per command, kept in LDS; very long programs go without.
     // An empty scene evaluates to max_dist everywhere (wgsl:189-191): no ray can hit unless
     // max_dist < min_dist, so (only) then the all-miss shortcut must stay off.
-    bool cull = c->cull && L.n_rec <= 256u;
+    bool cull = c->cull && L.n_rec <= 256u && !c->decoded.has_extensions;  // v3's cone table knows spheres and boxes only
     if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;
     L.n_cull = cull ? L.n_rec : 0u;
     L.flags = cull ? 1u : 0u;
@@ -260,10 +262,16 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         L.stats = c->d_stats;
     }
     if (int rc = time_begin(c, s)) return rc;
-    if (lds)
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    // reference-only programs run the lean interpreter; extension node types select the wider one
+    const bool ext = c->decoded.has_extensions;
+    if (lds && !ext)
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    else if (lds)
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+    else if (!ext)
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     else
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
 }
@@ -283,6 +291,8 @@ int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStre
 
 int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
     RmLaunch L = L_in;
+    if (c->decoded.has_extensions)
+        return fail(c, RM_ERR_ARG, "the v4 kernels render reference node types only (program uses extension nodes)");
     bool cull = c->cull && L.n_rec <= 256u;
     if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi
     L.n_cull = cull ? L.n_rec : 0u;
@@ -313,6 +323,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.flags = 0;
     L.n_cone = c->decoded.n_sphere;
     L.n_slab = c->decoded.n_box;
+    L.smooth_slack = (float)c->decoded.smooth_slack;
     L.min_dist = c->limits.min_dist;
     L.max_dist = c->limits.max_dist;
     L.max_iter = c->limits.max_iter;
@@ -323,8 +334,11 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.stats = nullptr;
     L.u = c->uniforms;
     int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_V5_LDS : c->kernel;
-    if (kernel == RM_KERNEL_RAYPOOL || kernel == RM_KERNEL_RAYPOOL_LDS || kernel == RM_KERNEL_PIXEL)
+    if (kernel == RM_KERNEL_RAYPOOL || kernel == RM_KERNEL_RAYPOOL_LDS || kernel == RM_KERNEL_PIXEL) {
+        if (c->decoded.has_extensions)
+            return fail(c, RM_ERR_ARG, "kernel variant %d renders reference node types only (program uses extension nodes)", kernel);
         if (int rc = time_begin(c, s)) return rc;
+    }
     switch (kernel) {
     case RM_KERNEL_RAYPOOL:
     case RM_KERNEL_RAYPOOL_LDS: {

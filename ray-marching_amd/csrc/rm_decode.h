@@ -13,7 +13,10 @@ struct RmDecoded {
     uint32_t n_words = 0;      // words consumed by cmd_count commands
     uint32_t max_depth = 0;    // value-stack depth of the reference machine
     uint32_t spill_depth = 0;  // LDS slots the accumulator machine needs
-    uint32_t n_sphere = 0, n_box = 0;  // primitives per kind; RmRecord::p[6] holds each one's slot within its kind
+    uint32_t n_sphere = 0, n_box = 0;  // cone / slab entries of the miss-test tables; RmRecord::p[6] = slot
+    uint32_t n_plane = 0;              // unbounded primitives: they veto miss-ray culling
+    bool has_extensions = false;       // uses node types the reference does not implement
+    double smooth_slack = 0.0;         // sum of k/4 over SmoothUnion operators
 };
 
 // Returns RM_OK or a negative rm_status.  `cap_words` is the number of u32 words that
@@ -30,22 +33,30 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
         uint32_t op = words[ptr++];
         RmRecord r;
         std::memset(&r, 0, sizeof r);
-        if (op == RM_CMD_SPHERE || op == RM_CMD_BOX) {
-            uint32_t np = op == RM_CMD_SPHERE ? 4u : 6u;
+        uint32_t kind = RM_KIND_POP, np = 0;
+        switch (op) {
+        case RM_CMD_SPHERE: kind = RM_KIND_SPHERE; np = 4; break;
+        case RM_CMD_BOX: kind = RM_KIND_BOX; np = 6; break;
+        case RM_CMD_CYLINDER: kind = RM_KIND_CYLINDER; np = 5; d.has_extensions = true; break;
+        case RM_CMD_PLANE: kind = RM_KIND_PLANE; np = 4; d.has_extensions = true; d.n_plane++; break;
+        default: break;
+        }
+        if (kind != RM_KIND_POP) {
             if (ptr + np > cap_words) return RM_ERR_TRUNCATED;
             std::memcpy(r.p, words + ptr, np * 4);
             ptr += np;
-            uint32_t kind = op == RM_CMD_SPHERE ? RM_KIND_SPHERE : RM_KIND_BOX;
-            const uint32_t slot = op == RM_CMD_SPHERE ? d.n_sphere++ : d.n_box++;
-            std::memcpy(&r.p[6], &slot, 4);  // slot in the kernels' per-kind miss-test tables
-            // Fuse with a directly following binary operator: its rhs is this leaf.
+            // slot in the kernels' per-kind miss-test tables: cones for spheres, slabs for boxes and cylinders
+            const uint32_t slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : (kind == RM_KIND_PLANE ? 0u : d.n_box++);
+            std::memcpy(&r.p[6], &slot, 4);
+            // Fuse with a directly following parameter-less binary operator: its rhs is this leaf.
             uint32_t mode = RM_MODE_PUSH;
             if (i + 1 < cmd_count && ptr < cap_words && depth >= 1) {
                 if (words[ptr] == RM_CMD_UNION) mode = RM_MODE_UNION;
                 else if (words[ptr] == RM_CMD_SUBTRACTION) mode = RM_MODE_SUB;
+                else if (words[ptr] == RM_CMD_INTERSECTION) { mode = RM_MODE_INTER; d.has_extensions = true; }
             }
             if (mode != RM_MODE_PUSH) {
-                ptr++;  // consume the operator: depth is unchanged (push then pop 2 push 1)
+                ptr++;  // consume the operator: depth is unchanged (push, then pop 2 push 1)
                 i++;
                 if (depth + 1 > 32) return RM_ERR_STACK_OVERFLOW;  // the reference machine peaks one higher
                 if (depth + 1 > d.max_depth) d.max_depth = depth + 1;
@@ -59,12 +70,22 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
                 r.op = RM_OP(kind, RM_MODE_PUSH, spill);
             }
             d.rec.push_back(r);
-            // a fused record stands for two reference commands; keep n_rec == records
-        } else if (op == RM_CMD_UNION || op == RM_CMD_SUBTRACTION) {
+        } else if (op == RM_CMD_UNION || op == RM_CMD_SUBTRACTION || op == RM_CMD_INTERSECTION ||
+                   op == RM_CMD_SMOOTH_UNION) {
+            uint32_t mode = op == RM_CMD_UNION ? RM_MODE_UNION : op == RM_CMD_SUBTRACTION ? RM_MODE_SUB
+                          : op == RM_CMD_INTERSECTION ? RM_MODE_INTER : RM_MODE_SMOOTH;
+            if (op == RM_CMD_SMOOTH_UNION) {  // one parameter: k
+                if (ptr + 1 > cap_words) return RM_ERR_TRUNCATED;
+                std::memcpy(&r.p[0], words + ptr, 4);
+                ptr += 1;
+                if (r.p[0] > 0.0f) d.smooth_slack += (double)r.p[0] * 0.25;
+                else if (!(r.p[0] <= 0.0f)) d.smooth_slack = 1.0 / 0.0;  // NaN k: nothing can be bounded
+            }
+            if (op == RM_CMD_INTERSECTION || op == RM_CMD_SMOOTH_UNION) d.has_extensions = true;
             if (depth < 2) return RM_ERR_STACK_UNDERFLOW;
             depth--;
             spilled--;
-            r.op = RM_OP(RM_KIND_POP, op == RM_CMD_UNION ? RM_MODE_UNION : RM_MODE_SUB, 0);
+            r.op = RM_OP(RM_KIND_POP, mode, 0);
             d.rec.push_back(r);
         } else {
             return RM_ERR_OPCODE;

@@ -19,17 +19,25 @@
 // The arithmetic performed on each value is exactly the reference's, in the same order;
 // only the bookkeeping (where a value lives) changes.
 struct RmRecord {
-    uint32_t op;  // kind | mode<<2 | spill<<4
-    float p[7];   // sphere: cx cy cz r          box: cx cy cz rx ry rz
+    uint32_t op;  // kind | mode<<3 | spill<<6
+    float p[7];   // sphere: cx cy cz r   box: cx cy cz rx ry rz   cylinder: cx cy cz r half_h
+                  // plane: nx ny nz h    POP+SMOOTH: k            p[6] (primitives): slot in the miss-test tables
 };
 static_assert(sizeof(RmRecord) == 32, "record must be 32 bytes");
 
-enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2 };
-enum : uint32_t { RM_MODE_PUSH = 0, RM_MODE_UNION = 1, RM_MODE_SUB = 2 };
-#define RM_OP(kind, mode, spill) ((uint32_t)(kind) | ((uint32_t)(mode) << 2) | ((uint32_t)(spill) << 4))
+enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2, RM_KIND_CYLINDER = 3, RM_KIND_PLANE = 4 };
+enum : uint32_t { RM_MODE_PUSH = 0, RM_MODE_UNION = 1, RM_MODE_SUB = 2, RM_MODE_INTER = 3, RM_MODE_SMOOTH = 4 };
+#define RM_OP(kind, mode, spill) ((uint32_t)(kind) | ((uint32_t)(mode) << 3) | ((uint32_t)(spill) << 6))
+#define RM_OP_KIND(op) ((op) & 7u)
+#define RM_OP_MODE(op) (((op) >> 3) & 7u)
+enum : uint32_t { RM_OP_SPILL = 1u << 6 };
 
 // reference opcodes (csg/builder.rs:1-24)
 enum : uint32_t { RM_CMD_SPHERE = 0, RM_CMD_BOX = 1, RM_CMD_UNION = 100, RM_CMD_SUBTRACTION = 101 };
+// Extension opcodes (not implemented by the reference; DESIGN.md "Extension node types").  Plane and
+// Intersection use the slots the reference reserves by comment (builder.rs:8,14); Cylinder and
+// SmoothUnion (BASELINE.json configs 2-3) stay clear of every reserved slot (2, 102, 200-205).
+enum : uint32_t { RM_CMD_PLANE = 2, RM_CMD_CYLINDER = 10, RM_CMD_INTERSECTION = 102, RM_CMD_SMOOTH_UNION = 110 };
 
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
@@ -37,7 +45,8 @@ struct RmLaunch {
     uint32_t spill_depth;      // LDS value-stack slots per lane this program needs
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
     uint32_t flags;            // bit 0: miss-ray culling enabled
-    uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / boxes of the program
+    uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program
+    float smooth_slack;        // sum of k/4 over SmoothUnion operators: how far they can lower the tree value
     float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
     uint32_t max_iter;
     uint32_t W, H, row0, rows;

@@ -62,6 +62,22 @@ RMH_EXPORT rmh_node* rmh_subtraction(const rmh_node* lhs, const rmh_node* rhs) {
     if (!lhs || !rhs) return nullptr;
     return new (std::nothrow) rmh_node{csg::make_subtraction(lhs->node, rhs->node)};
 }
+RMH_EXPORT rmh_node* rmh_plane(const float normal[3], float h) {
+    if (!normal) return nullptr;
+    return new (std::nothrow) rmh_node{csg::CSGNode(csg::Plane{a3(normal), h})};
+}
+RMH_EXPORT rmh_node* rmh_cylinder(const float center[3], float radius, float half_height) {
+    if (!center) return nullptr;
+    return new (std::nothrow) rmh_node{csg::CSGNode(csg::Cylinder{a3(center), radius, half_height})};
+}
+RMH_EXPORT rmh_node* rmh_intersection(const rmh_node* lhs, const rmh_node* rhs) {
+    if (!lhs || !rhs) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_intersection(lhs->node, rhs->node)};
+}
+RMH_EXPORT rmh_node* rmh_smooth_union(const rmh_node* lhs, const rmh_node* rhs, float k) {
+    if (!lhs || !rhs) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_smooth_union(lhs->node, rhs->node, k)};
+}
 RMH_EXPORT rmh_node* rmh_node_clone(const rmh_node* n) { return n ? new (std::nothrow) rmh_node{n->node} : nullptr; }
 RMH_EXPORT void rmh_node_free(rmh_node* n) { delete n; }
 RMH_EXPORT rmh_node* rmh_scene(const char* name) {

@@ -73,15 +73,27 @@ RM_DEV float sdf_box_t(float px, float py, float pz, const float (&p)[7], uint32
     return sqrt_sel<FAST>((mx * mx + my * my) + mz * mz, tiny) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f);
 }
 
+template <bool FAST>
+RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], uint32_t& tiny) {
+    // extension: capped cylinder along y.  p = cx cy cz radius half_height
+    const float dx = px - p[0], dz = pz - p[2];
+    const float qx = sqrt_sel<FAST>(dx * dx + dz * dz, tiny) - p[3];
+    const float qy = __builtin_fabsf(py - p[1]) - p[4];
+    const float mx = fmax_(qx, 0.0f), my = fmax_(qy, 0.0f);
+    return fmin_(fmax_(qx, qy), 0.0f) + sqrt_sel<FAST>(mx * mx + my * my, tiny);
+}
+
 // One decoded command applied to the R positions of a lane.
-template <int R, bool FAST>
+// EXT = false compiles the reference's four node types only (the lean, measured path); EXT = true
+// adds the extension node types.  Which one runs is decided per program on the host.
+template <int R, bool FAST, bool EXT = false>
 RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R], const float (&qy)[R],
                          const float (&qz)[R], float (&acc)[R], float* spill, uint32_t& sp, uint32_t& tiny) {
     // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
     op = __builtin_amdgcn_readfirstlane(op);
-    const uint32_t kind = op & 3u, mode = (op >> 2) & 3u;
+    const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
     float a[R], b[R];
     if (kind == RM_KIND_POP) {
         --sp;
@@ -94,11 +106,17 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R],
         if (kind == RM_KIND_SPHERE) {
 #pragma unroll
             for (int k = 0; k < R; k++) b[k] = sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
-        } else {
+        } else if (!EXT || kind == RM_KIND_BOX) {
 #pragma unroll
             for (int k = 0; k < R; k++) b[k] = sdf_box_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+        } else if (kind == RM_KIND_CYLINDER) {  // extension
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = sdf_cylinder_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+        } else {  // RM_KIND_PLANE, extension: dot(pos, n) + h
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = ((qx[k] * p[0] + qy[k] * p[1]) + qz[k] * p[2]) + p[3];
         }
-        if (op >> 4) {
+        if (op & RM_OP_SPILL) {
 #pragma unroll
             for (int k = 0; k < R; k++) spill[(sp * R + k) * 64u] = acc[k];
             ++sp;
@@ -112,16 +130,30 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R],
     } else if (mode == RM_MODE_UNION) {
 #pragma unroll
         for (int k = 0; k < R; k++) acc[k] = vmin(a[k], b[k]);  // wgsl:242-246
-    } else {
+    } else if (!EXT || mode == RM_MODE_SUB) {
 #pragma unroll
         for (int k = 0; k < R; k++) acc[k] = vmax_negb(a[k], b[k]);  // wgsl:248-252
+    } else if (mode == RM_MODE_INTER) {  // extension: max(a, b)
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = fmax_(a[k], b[k]);
+    } else {  // RM_MODE_SMOOTH, extension: min(a,b) - h*h*k/4, h = max(k - |a-b|, 0)/k; k <= 0: plain min
+        const float kk = p[0];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            float v = fmin_(a[k], b[k]);
+            if (kk > 0.0f) {
+                const float h = fmax_(kk - __builtin_fabsf(a[k] - b[k]), 0.0f) / kk;
+                v = v - ((h * h) * kk) * 0.25f;
+            }
+            acc[k] = v;
+        }
     }
 }
 
 // map_scene (wgsl:187-203) for R positions per lane.  Commands are fetched one ahead of their
 // use (two buffers, loop unrolled by two) so that the fetch latency hides behind the VALU work
 // of the previous command.
-template <int R, bool FAST, class Prog>
+template <int R, bool FAST, class Prog, bool EXT = false>
 RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx)[R],
                             const float (&qy)[R], const float (&qz)[R], float (&out)[R], uint32_t& tiny) {
     if (n_rec == 0u) {  // wgsl:189-191
@@ -138,10 +170,10 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     prog.load(0u, op0, p0);
     for (;;) {
         prog.load(c + 1u < n_rec ? c + 1u : c, op1, p1);
-        exec_command<R, FAST>(op0, p0, qx, qy, qz, acc, spill, sp, tiny);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny);
         if (++c == n_rec) break;
         prog.load(c + 1u < n_rec ? c + 1u : c, op0, p0);
-        exec_command<R, FAST>(op1, p1, qx, qy, qz, acc, spill, sp, tiny);
+        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny);
         if (++c == n_rec) break;
     }
 #pragma unroll
@@ -161,7 +193,7 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
 // primitive.  All slack is on the safe side (a ray that is not provably clear is marched).
 // ---------------------------------------------------------------------------------------------
 RM_DEV float4 cull_entry(const RmRecord& rec, const V4& ro, float min_dist) {
-    const uint32_t kind = rec.op & 3u;
+    const uint32_t kind = RM_OP_KIND(rec.op);  // v3 culls only reference-only programs (spheres and boxes)
     const float inf = __uint_as_float(0x7F800000u);
     if (kind == RM_KIND_POP) return make_float4(0.0f, 0.0f, 0.0f, inf);  // operators constrain nothing
     float rho;

@@ -43,16 +43,20 @@ struct CullTables {
     uint32_t n_cone, n_slab;
 };
 
-RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, float min_dist) {
+// `slack`: how far SmoothUnion operators can pull the tree value below the minimum over its leaves
+// (each lowers min(a,b) by at most k/4; nested operators add up).  0 for reference-only programs.
+RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, float min_dist, float slack) {
     const float scale = 1.0f + __builtin_fabsf(cx) + __builtin_fabsf(cy) + __builtin_fabsf(cz) + rho +
-                        __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z);
-    return fmax_(min_dist, 0.0f) * 1.01f + 1.0e-4f * scale;
+                        __builtin_fabsf(ro.x) + __builtin_fabsf(ro.y) + __builtin_fabsf(ro.z) + slack;
+    return (fmax_(min_dist, 0.0f) + slack) * 1.01f + 1.0e-4f * scale;
 }
 
 // Table entry (or entries) of one record; no-op for operators.  Called once per record per workgroup.
-RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, float4* cone, float4* slab, uint32_t* veto) {
-    const uint32_t kind = rec.op & 3u;
+RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, float slack, float4* cone, float4* slab,
+                          uint32_t* veto) {
+    const uint32_t kind = RM_OP_KIND(rec.op);
     if (kind == RM_KIND_POP) return;
+    if (kind == RM_KIND_PLANE) { *veto = 1u; return; }  // unbounded primitive: nothing can be culled
     const float inf = __uint_as_float(0x7F800000u);
     const uint32_t slot = __float_as_uint(rec.p[6]);
     const float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2];
@@ -62,7 +66,7 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
     if (kind == RM_KIND_SPHERE) {
         const float rho = fmax_(rec.p[3], 0.0f);
         finite = finite && rho < inf;
-        const float Rk = rho + cull_margin(cx, cy, cz, rho, ro, min_dist);
+        const float Rk = rho + cull_margin(cx, cy, cz, rho, ro, min_dist, slack);
         const float mx = cx - ro.x, my = cy - ro.y, mz = cz - ro.z;
         const float mm = mx * mx + my * my + mz * mz;
         // s < sqrt(|m|^2 - Rk^2), the slack covering the rounding of this computation and of the
@@ -72,13 +76,15 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
         if (lim > 0.0f && lim < inf) sv = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
         cone[slot] = make_float4(mx, my, mz, sv);
     } else {
-        const float hx = fmax_(rec.p[3], 0.0f), hy = fmax_(rec.p[4], 0.0f), hz = fmax_(rec.p[5], 0.0f);
+        // box: half extents; cylinder (extension): its bounding box (radius, half height, radius)
+        const bool cyl = kind == RM_KIND_CYLINDER;
+        const float hx = fmax_(rec.p[3], 0.0f), hy = fmax_(rec.p[4], 0.0f), hz = cyl ? hx : fmax_(rec.p[5], 0.0f);
         finite = finite && hx < inf && hy < inf && hz < inf;
-        const float M = cull_margin(cx, cy, cz, hx + hy + hz, ro, min_dist);
+        const float M = cull_margin(cx, cy, cz, hx + hy + hz, ro, min_dist, slack);
         slab[2u * slot] = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
         slab[2u * slot + 1u] = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 0.0f);
     }
-    if (!finite) *veto = 1u;
+    if (!finite || !(slack < inf)) *veto = 1u;
 }
 
 // true iff the half-line o + t d (t >= 0) provably stays clear of every primitive's margin zone.
@@ -117,7 +123,7 @@ struct V5Work {
 // takes the next tile of the work list with one atomic and leaves when the list is exhausted
 // (no spinning, no inter-workgroup dependency).  Tiles whose 1024 rays are all culled never reach
 // this kernel: the pre-pass writes their pixels directly.
-template <class Prog, bool PROG_IN_LDS, int WPT>
+template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT>
 __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
     constexpr uint32_t POOL = 1024u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();
     if (L.flags & 1u)
-        for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, t_cone, t_slab, s_veto);
+        for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
 
     Prog prog;
     if constexpr (PROG_IN_LDS) prog.base = lprog;
@@ -272,9 +278,9 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
             float qx[1], qy[1], qz[1], v[1];
             qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
             uint32_t tiny = 0xFFFFFFFFu;
-            map_scene_multi<1, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
             if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
-                map_scene_multi<1, false>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
             const float sd = v[0];
             if (mode == M_MARCH) {
                 if (sd < L.min_dist) {  // wgsl:97: hit -> normal taps around pos = q
@@ -403,7 +409,7 @@ __global__ __launch_bounds__(256) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();
     if (L.flags & 1u)
-        for (uint32_t k = tid; k < L.n_rec; k += 256u) cull_build_v5(L.prog[k], ro, L.min_dist, t_cone, t_slab, s_veto);
+        for (uint32_t k = tid; k < L.n_rec; k += 256u) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
     const uint32_t tiles_x = (L.W + 7u) / 8u;
   for (uint32_t tile = blockIdx.x * V5_PRE_TILES; tile < n_tiles && tile < (blockIdx.x + 1u) * V5_PRE_TILES; tile++) {
     if (tid == 0u) *s_surv = 0u;

@@ -132,7 +132,7 @@ RM_DEV float map_scene(const Prog& prog, uint32_t n_rec, const SpillLds& st, flo
         float p[7];
         prog.load(c, op, p);
         op = __builtin_amdgcn_readfirstlane(op);
-        const uint32_t kind = op & 3u, mode = (op >> 2) & 3u;
+        const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);  // reference node types only (host rejects extensions here)
         float a, b;
         if (kind == RM_KIND_POP) {
             b = acc;
@@ -140,7 +140,7 @@ RM_DEV float map_scene(const Prog& prog, uint32_t n_rec, const SpillLds& st, flo
         } else {
             float v = kind == RM_KIND_SPHERE ? sdf_sphere(px, py, pz, p[0], p[1], p[2], p[3])
                                              : sdf_box(px, py, pz, p[0], p[1], p[2], p[3], p[4], p[5]);
-            if (op >> 4) st.push(sp++, acc);
+            if (op & RM_OP_SPILL) st.push(sp++, acc);
             a = acc;
             b = v;
         }

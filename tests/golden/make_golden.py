@@ -30,6 +30,10 @@ CASES = [
     ("g64_48x40", "g64", 48, 40, (0.01, 100.0, 512), scenes.STILL_CAMERA_EVENTS),
     ("empty_40x24", None, 40, 24, (0.01, 100.0, 37), scenes.STILL_CAMERA_EVENTS),
     ("g8_inside_56", "g8", 56, 56, (0.01, 100.0, 100), [(2, -95.0, 0.0)]),   # camera dollied inside the solid
+    # extension node types (semantics defined by this repo, not by the reference)
+    ("g8x_64", "g8x", 64, 64, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),
+    ("g32s_64", "g32s", 64, 64, (0.01, 100.0, 256), scenes.STILL_CAMERA_EVENTS),
+    ("ext_mix_64x48", "ext_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),
 ]
 # larger renders pinned by checksum + counters only
 BIG = [
@@ -43,7 +47,7 @@ def inputs(scene, W, H, events):
     if scene is None:
         cc, words = 0, np.zeros(0, dtype=np.uint32)
     else:
-        cc, words = cbind.serialize(*scenes.SCENES[scene]())
+        cc, words = cbind.serialize(*{**scenes.SCENES, **scenes.EXT_SCENES}[scene]())
     u, *_ = cbind.orbit_uniforms((float(W), float(H)), events=events)
     return cc, words, u
 

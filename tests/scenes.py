@@ -3,6 +3,7 @@ scene generator (ray-marching_amd/csrc/host/scenes.hpp) so that the two can be c
 word for word.  A scene is (nodes, root) with nodes = [(kind, params, lhs, rhs), ...] in the
 flat-table form oracle.cbind.serialize() takes."""
 SPHERE, BOX, UNION, SUBTRACTION = 0, 1, 100, 101
+PLANE, CYLINDER, INTERSECTION, SMOOTH_UNION = 2, 10, 102, 110    # extension node types (DESIGN.md)
 
 
 def _f32(x):
@@ -24,6 +25,19 @@ class _Tab:
 
     def op(self, kind, a, b):
         self.nodes.append((kind, [], a, b))
+        return len(self.nodes) - 1
+
+    # extension node types
+    def plane(self, n, h):
+        self.nodes.append((PLANE, [n[0], n[1], n[2], h], -1, -1))
+        return len(self.nodes) - 1
+
+    def cylinder(self, c, r, half_h):
+        self.nodes.append((CYLINDER, [c[0], c[1], c[2], r, half_h], -1, -1))
+        return len(self.nodes) - 1
+
+    def smooth_union(self, a, b, k):
+        self.nodes.append((SMOOTH_UNION, [k], a, b))
         return len(self.nodes) - 1
 
 
@@ -110,7 +124,38 @@ def right_deep(n):
     return t.nodes, acc
 
 
+def g8x():
+    """BASELINE config 2 as literally worded: sphere U box - cylinder (+ floor slab).  Extension."""
+    t = _Tab()
+    s0 = t.sphere((0, 0, 0), 1.0)
+    b1 = t.box((0, 0, 0), (0.8, 0.8, 0.8))
+    c2 = t.cylinder((0.9, 0.5, 0.6), 0.45, 0.9)
+    b3 = t.box((0, -1.2, 0), (1.5, 0.1, 1.5))
+    root = t.op(UNION, t.op(SUBTRACTION, t.op(UNION, s0, b1), c2), b3)
+    return t.nodes, root
+
+
+def g32s():
+    """BASELINE config 3 as literally worded: G32 with Union -> SmoothUnion(k = 0.25).  Extension."""
+    t = _Tab()
+    prims = _grid_prims(t, 4, 4, 0x5DF00020)
+    acc = prims[0]
+    for k in range(len(prims) - 1):
+        acc = t.op(SUBTRACTION, acc, prims[k + 1]) if k % 4 == 3 else t.smooth_union(acc, prims[k + 1], 0.25)
+    return t.nodes, acc
+
+
+def ext_mix():
+    """Every extension node type in one tree: plane-cut, intersection, cylinder, smooth blends."""
+    t = _Tab()
+    a = t.smooth_union(t.sphere((-0.6, 0, 0), 0.7), t.cylinder((0.5, 0.0, 0.1), 0.4, 0.8), 0.3)
+    b = t.op(INTERSECTION, t.box((0, 0, 0), (1.4, 0.9, 1.0)), t.plane((0.0, 1.0, 0.2), 0.35))
+    c = t.smooth_union(a, t.op(SUBTRACTION, b, t.sphere((0.2, 0.3, 0.9), 0.5)), 0.15)
+    return t.nodes, t.op(UNION, c, t.cylinder((-1.4, -0.6, -0.5), 0.25, 0.5))
+
+
 SCENES = {"g1": g1, "g8": g8, "g32": g32, "g64": g64, "g32_balanced": g32_balanced}
+EXT_SCENES = {"g8x": g8x, "g32s": g32s, "ext_mix": ext_mix}
 
 # (events for OrbitCameraController::update) still camera of SURVEY 8(d): Orbit([35,-25])
 STILL_CAMERA_EVENTS = [(1, 35.0, -25.0)]

@@ -51,6 +51,8 @@ def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kern
 @pytest.mark.parametrize("name", sorted(n for n in IDX if "file" in IDX[n]))
 def test_golden_fixtures(res, name, kernel):
     e = IDX[name]
+    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS):
+        pytest.skip("only the v5 kernels render extension node types")
     u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
     setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
     assert_same(res.draw(e["W"], e["H"]), G.load_image(e))
@@ -235,6 +237,54 @@ def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     with pytest.raises(_ffi.RmError):
         res.draw_strips(W, H, 12, 0, 2)          # strip height must be a multiple of 16
     assert res.draw_strips(W, H, 32, 7, 8).shape[0] == 0   # more ranks than strips: empty share
+
+
+EXT_KERNELS = [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]     # older kernels: reference nodes only
+EXT_IDS = ["default", "v5", "v5_lds"]
+
+
+@pytest.mark.parametrize("kernel", EXT_KERNELS, ids=EXT_IDS)
+@pytest.mark.parametrize("name", sorted(scenes.EXT_SCENES))
+def test_extension_node_types_vs_oracle(res, oracle, name, kernel):
+    """Plane / Cylinder / Intersection / SmoothUnion (not in the reference; BASELINE configs 2-3):
+    bit-exact against the oracle, with miss-ray culling on and off, for several cameras."""
+    W, H = 88, 56
+    cc, w = oracle.serialize(*scenes.EXT_SCENES[name]())
+    for events in (scenes.STILL_CAMERA_EVENTS, [(1, -70.0, 40.0), (2, 60.0, 0.0)], [(2, -93.0, 0.0)]):
+        u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+        for lim in [(0.01, 100.0, 128), (0.4, 60.0, 48)]:
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            for cull in (0, 1):
+                res.set_option(_ffi.RM_OPT_CULL, cull)
+                assert_same(res.draw(W, H), ref)
+    res.set_option(_ffi.RM_OPT_CULL, 1)
+
+
+def test_reference_only_kernels_reject_extension_programs(res, oracle):
+    cc, w = oracle.serialize(*scenes.g8x())
+    u, *_ = oracle.orbit_uniforms((16.0, 16.0))
+    for kernel in (_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE):
+        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=(0.01, 100.0, 16), kernel=kernel)
+        with pytest.raises(_ffi.RmError) as e:
+            res.draw(16, 16)
+        assert e.value.status == _ffi.RM_ERR_ARG
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+
+
+def test_baseline_config2_and_3_as_worded(res, oracle):
+    """BASELINE.json configs[1] (1920x1080, sphere U box - cylinder, 128 steps) and configs[2]
+    (32-node graph with smooth-min blends, 256 steps; at 1920x1080 here) on the default kernel:
+    sampled row bands bit-exact against the oracle + full-frame sanity."""
+    for name, lim in (("g8x", (0.01, 100.0, 128)), ("g32s", (0.01, 100.0, 256))):
+        W, H = 1920, 1080
+        cc, w = oracle.serialize(*scenes.EXT_SCENES[name]())
+        u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
+        full = res.draw(W, H)
+        assert np.isfinite(full).all() and np.array_equal(full[..., 3], np.ones((H, W), np.float32))
+        for r0, rows in [(300, 4), (520, 6), (700, 4)]:
+            assert_same(full[r0:r0 + rows], oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=8))
 
 
 def test_raw_write_buffer_path_and_stale_tail(res, oracle):
