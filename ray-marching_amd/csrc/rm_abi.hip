@@ -216,7 +216,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     L.flags = cull ? 1u : 0u;
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
     if (!cull) L.n_cone = L.n_slab = 0u;
-    const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 32u;
+    const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;
     const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
@@ -278,7 +278,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
     int wpt = c->waves_per_tile;
-    const size_t fixed = 4096u + (size_t)L.n_rec * (32u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
+    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
     while (wpt > 1 && fixed + (size_t)wpt * ((4u * rmk::V5_RQ + 7u * rmk::V5_SQ) * 4u + (size_t)L.spill_depth * 256u) > 48u * 1024u)
         wpt /= 2;
     switch (wpt) {

@@ -34,7 +34,9 @@ constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
 // Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
 // decoder stores each primitive's slot within its kind in RmRecord::p[6]):
 //   cone[n_cone]  one float4 per sphere: (m.x, m.y, m.z, s); a ray clears it iff m.d - s < 0
-//   slab[n_slab]  two float4 per box: lo - o and hi - o of the box inflated by the margin
+//   slab[n_slab]  three float4 per box / cylinder: lo - o and hi - o of the bounding box inflated by
+//                 the margin, then the cone of that box's bounding sphere (a cheap pre-test: only
+//                 if some lane's ray enters that cone does the wave run the 6-multiply slab test)
 //   veto          set when anything is non-finite: then nothing is culled
 struct CullTables {
     const float4* cone;
@@ -81,8 +83,16 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
         const float hx = fmax_(rec.p[3], 0.0f), hy = fmax_(rec.p[4], 0.0f), hz = cyl ? hx : fmax_(rec.p[5], 0.0f);
         finite = finite && hx < inf && hy < inf && hz < inf;
         const float M = cull_margin(cx, cy, cz, hx + hy + hz, ro, min_dist, slack);
-        slab[2u * slot] = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
-        slab[2u * slot + 1u] = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 0.0f);
+        slab[3u * slot] = make_float4((cx - hx - M) - ro.x, (cy - hy - M) - ro.y, (cz - hz - M) - ro.z, 0.0f);
+        slab[3u * slot + 1u] = make_float4((cx + hx + M) - ro.x, (cy + hy + M) - ro.y, (cz + hz + M) - ro.z, 0.0f);
+        // bounding-sphere cone of the inflated box (same construction as for spheres)
+        const float Rk = __builtin_sqrtf((hx + M) * (hx + M) + (hy + M) * (hy + M) + (hz + M) * (hz + M)) * (1.0f + 1.0e-5f);
+        const float mx = cx - ro.x, my = cy - ro.y, mz = cz - ro.z;
+        const float mm = mx * mx + my * my + mz * mz;
+        const float lim = mm * (1.0f - 4.0e-6f) - Rk * Rk * (1.0f + 4.0e-6f);
+        float sv = -inf;  // origin not clearly outside the bounding sphere: always run the slab test
+        if (lim > 0.0f && lim < inf) sv = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
+        slab[3u * slot + 2u] = make_float4(mx, my, mz, sv);
     }
     if (!finite || !(slack < inf)) *veto = 1u;
 }
@@ -103,12 +113,15 @@ RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float d
     const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dy), tiny), dy));
     const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(dz), tiny), dz));
     for (uint32_t k = 0; k < T.n_slab; k++) {
-        const float4 a = T.slab[2u * k], b = T.slab[2u * k + 1u];
+        const float4 c = T.slab[3u * k + 2u];
+        const float t = __builtin_fmaf(c.z, dz, __builtin_fmaf(c.y, dy, __builtin_fmaf(c.x, dx, -c.w)));
+        if (__ballot(clear && !(t < 0.0f)) == 0ull) continue;  // every still-clear ray misses the bounding sphere
+        const float4 a = T.slab[3u * k], b = T.slab[3u * k + 1u];
         const float x1 = a.x * ix, x2 = b.x * ix, y1 = a.y * iy, y2 = b.y * iy, z1 = a.z * iz, z2 = b.z * iz;
         const float tn = fmax_(fmin_(x1, x2), fmax_(fmin_(y1, y2), fmin_(z1, z2)));
         const float tf = fmin_(fmax_(x1, x2), fmin_(fmax_(y1, y2), fmax_(z1, z2)));
         clear = clear && !(tf >= fmax_(tn, 0.0f));  // a dropped NaN only widens the interval
-        if ((k & 1u) == 1u && __ballot(clear) == 0ull) return false;
+        if (__ballot(clear) == 0ull) return false;
     }
     return clear;
 }
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
     float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(t_slab + 2u * L.n_slab);
+    uint32_t* lprog = reinterpret_cast<uint32_t*>(t_slab + 3u * L.n_slab);
     uint32_t* s_next = lprog + (PROG_IN_LDS ? L.n_rec * 8u : 0u);      // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
     uint32_t* s_veto = s_next + 2;

@@ -428,3 +428,50 @@ def test_device_output_and_stream(res, oracle):
 def test_write_bandwidth_calibration(res):
     gbps = res.measure_write_bandwidth(1 << 28, 5)
     assert 200.0 < gbps < 9000.0
+
+
+def test_two_contexts_from_two_threads(oracle):
+    """Different contexts may be used concurrently from different threads (rm_abi.h threading note)."""
+    import threading
+    W, H = 96, 64
+    jobs = [("g8", (0.01, 100.0, 64)), ("g32", (0.01, 100.0, 96))]
+    out, err = {}, []
+
+    def work(i):
+        try:
+            name, lim = jobs[i]
+            r = renderer.RayMarchingResources(0)
+            cc, w = oracle.serialize(*scenes.SCENES[name]())
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+            r.set_limits(lim)
+            r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+            r.set_program(cc, w)
+            imgs = [r.draw(W, H) for _ in range(6)]
+            out[i] = (imgs, oracle.render(u, lim, cc, w, W, H, threads=2))
+            r.close()
+        except Exception as e:   # noqa: BLE001
+            err.append(e)
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    for i in range(2):
+        imgs, ref = out[i]
+        for img in imgs:
+            assert_same(img, ref)
+
+
+def test_host_output_rate_is_reported(res, oracle):
+    """PCIe-inclusive path (host destination): correct, and its rate is printed for DESIGN.md."""
+    import time
+    W, H = 1920, 1080
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=(0.01, 100.0, 256))
+    res.draw(W, H)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        img = res.draw(W, H)
+    dt = (time.perf_counter() - t0) / 5
+    print("host-destination draw 1920x1080: %.2f ms = %.0f Mpixels/s (PCIe + pageable-host copy included)" % (dt * 1e3, W * H / dt / 1e6))
+    assert img.shape == (H, W, 4)
