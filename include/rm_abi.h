@@ -183,6 +183,14 @@ int rm_get_info(rm_ctx* ctx, int key, double* out);
  * with 16 B/lane stores; reports the achieved GB/s (the measured HBM-write ceiling). */
 int rm_measure_write_bandwidth(rm_ctx* ctx, uint64_t bytes, int iters, double* out_gbps);
 
+/* Self-tests of the arithmetic building blocks (used by tests/test_gpu_arithmetic.py).
+ * rm_selftest_sqrt: runs the kernels' short correctly-rounded sqrt against the generic one on ALL 2^32 binary32
+ * bit patterns (restricted to its stated domain: 0, [2^-96, +inf], NaN); *out_mismatches must come back 0.
+ * rm_selftest_ops: out[k*n + i], k = 0..7: min(a,b), max(a,b), v_min_f32(a,b), v_max_f32(a,-b), short sqrt(a),
+ * generic sqrt(a), a / b, (float) i32(round(a)) -- compared on the host with the oracle's definitions. */
+int rm_selftest_sqrt(rm_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_bad_bits);
+int rm_selftest_ops(rm_ctx* ctx, const float* a, const float* b, float* out, uint32_t n);
+
 /* Diagnostics: per-wave records of the last draw made with RM_OPT_WAVE_STATS = 1, four u64 per
  * wave in dispatch order: [0] start, [1] end (100 MHz s_memrealtime ticks), [2] tile id << 32 |
  * map_scene iterations, [3] refills << 32 | sum over iterations of live lanes. */

@@ -95,6 +95,10 @@ def hip_lib():
         L.rm_set_option.argtypes = [vp, C.c_int, i64]
         L.rm_get_info.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
         L.rm_measure_write_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]
+        L.rm_selftest_sqrt.argtypes = [vp, C.POINTER(u64), C.POINTER(u32)]
+        L.rm_selftest_sqrt.restype = C.c_int
+        L.rm_selftest_ops.argtypes = [vp, vp, vp, vp, u32]
+        L.rm_selftest_ops.restype = C.c_int
         L.rm_read_wave_stats.argtypes = [vp, vp, u64, C.POINTER(u64)]
         L.rm_read_wave_stats.restype = C.c_int
         L.rm_last_error.argtypes = [vp]

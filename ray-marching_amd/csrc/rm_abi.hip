@@ -723,6 +723,49 @@ RM_EXPORT int rm_read_wave_stats(rm_ctx* c, void* dst, uint64_t cap_bytes, uint6
     return RM_OK;
 }
 
+RM_EXPORT int rm_selftest_sqrt(rm_ctx* c, uint64_t* out_mismatches, uint32_t* out_first_bad_bits) {
+    if (!c) return RM_ERR_NULL;
+    if (!out_mismatches || !out_first_bad_bits) return fail(c, RM_ERR_NULL, "rm_selftest_sqrt: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    unsigned long long* d_bad = nullptr;
+    uint32_t* d_first = nullptr;
+    HIP_TRY(c, hipMalloc(&d_bad, 8));
+    HIP_TRY(c, hipMalloc(&d_first, 4));
+    HIP_TRY(c, hipMemset(d_bad, 0, 8));
+    HIP_TRY(c, hipMemset(d_first, 0xFF, 4));
+    hipLaunchKernelGGL(rmk::rm_selftest_sqrt_kernel, dim3(std::max(1, c->cu_count) * 16), dim3(256), 0, c->stream, 0u,
+                       (uint64_t)1 << 32, d_bad, d_first);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(out_first_bad_bits, d_first, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    (void)hipFree(d_first);
+    if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "rm_selftest_sqrt: %s", hipGetErrorString(e));
+    *out_mismatches = bad;
+    return RM_OK;
+}
+
+RM_EXPORT int rm_selftest_ops(rm_ctx* c, const float* a, const float* b, float* out, uint32_t n) {
+    if (!c) return RM_ERR_NULL;
+    if (!a || !b || !out || n == 0u) return fail(c, RM_ERR_NULL, "rm_selftest_ops: NULL argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIP_TRY(c, hipMalloc(&da, (size_t)n * 4));
+    HIP_TRY(c, hipMalloc(&db, (size_t)n * 4));
+    HIP_TRY(c, hipMalloc(&dout, (size_t)n * 32));
+    hipError_t e = hipMemcpy(da, a, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(db, b, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rmk::rm_selftest_ops_kernel, dim3((n + 255u) / 256u), dim3(256), 0, c->stream, da, db, dout, n);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, (size_t)n * 32, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "rm_selftest_ops: %s", hipGetErrorString(e));
+    return RM_OK;
+}
+
 RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, double* out_gbps) {
     if (!c) return RM_ERR_NULL;
     if (!out_gbps) return fail(c, RM_ERR_NULL, "rm_measure_write_bandwidth: out is NULL");

@@ -19,7 +19,10 @@ namespace rmk {
 // v_min_f32 / v_max_f32 issued directly: the builtins make the compiler insert a canonicalising
 // v_max_f32 x,x in front of every operand it cannot prove quiet (values that went through a
 // phi or LDS), which costs two extra VALU per CSG operator.  Semantics are identical for every
-// non-signalling input (IEEE mode is on; -0 < +0; a NaN operand loses).
+// non-signalling input (IEEE mode is on; -0 < +0; a quiet NaN operand loses); a SIGNALLING NaN
+// operand would yield a quiet NaN instead of the other operand, but these are only ever applied to
+// results of arithmetic instructions (SDF values, accumulators), which are never signalling
+// (tests/test_gpu_arithmetic.py checks both facts).
 RM_DEV float vmin(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -516,6 +519,49 @@ __global__ __launch_bounds__(1024) void rm_tile_sort(const uint32_t* cost, uint3
         const uint32_t pos = atomicAdd(&base[64u - (c[i] < 64u ? c[i] : 64u)], 1u);
         o[pos] = i;
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-tests of the arithmetic building blocks (diagnostics, rm_selftest_* in the ABI).
+// ---------------------------------------------------------------------------------------------
+// Exhaustive: sqrt_rn_fast(x) == correctly rounded sqrt for EVERY binary32 x in its stated domain
+// (x == 0, x >= 2^-96, +inf, NaN), i.e. for all bit patterns in [first, first + count).
+__global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* mismatches,
+                                                               uint32_t* first_bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = first + (uint32_t)i;
+        const float x = __uint_as_float(bits);
+        const bool in_domain = (bits == 0u) || (bits >= 0x0F800000u && bits <= 0x7F800000u) || (x != x);
+        if (!in_domain) continue;  // negative numbers and (0, 2^-96): handled by the generic path
+        const float a = sqrt_rn_fast(x), b = __builtin_sqrtf(x);
+        const bool same = (a != a && b != b) || __float_as_uint(a) == __float_as_uint(b);
+        if (!same) {
+            bad++;
+            atomicMin(first_bad, bits);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// Element-wise results of the primitives the kernels rely on, for comparison with the oracle's
+// definitions on the host: out[0..7][i] = min, max, direct v_min, direct v_max(a,-b), fast sqrt(a),
+// generic sqrt(a), a / b, (float) i32(round(a)).
+__global__ __launch_bounds__(256) void rm_selftest_ops_kernel(const float* a, const float* b, float* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    out[0u * n + i] = fmin_(x, y);
+    out[1u * n + i] = fmax_(x, y);
+    out[2u * n + i] = vmin(x, y);
+    out[3u * n + i] = vmax_negb(x, y);
+    const uint32_t bits = __float_as_uint(x);
+    const bool in_domain = (bits == 0u) || (bits >= 0x0F800000u && bits <= 0x7F800000u) || (x != x);
+    out[4u * n + i] = in_domain ? sqrt_rn_fast(x) : __builtin_sqrtf(x);
+    out[5u * n + i] = __builtin_sqrtf(x);
+    out[6u * n + i] = x / y;
+    out[7u * n + i] = (float)__float2int_rz(__builtin_rintf(x));
 }
 
 }  // namespace rmk
