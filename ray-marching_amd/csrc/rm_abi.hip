@@ -132,6 +132,21 @@ int ensure_program(rm_ctx* c) {
     return RM_OK;
 }
 
+// Device scratch that only ever grows (allocated outside of any timed or captured region the first
+// time a size is seen; later draws of the same size allocate nothing).
+template <class T>
+int grow_device(rm_ctx* c, T** buf, size_t* cap, size_t need_elems) {
+    if (need_elems <= *cap) return RM_OK;
+    if (*buf) (void)hipFree(*buf);
+    *buf = nullptr;
+    *cap = 0;
+    HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(buf), need_elems * sizeof(T)));
+    *cap = need_elems;
+    return RM_OK;
+}
+int ensure_tile_buffers(rm_ctx* c, size_t n_tiles_total);
+int ensure_stats(rm_ctx* c, RmLaunch& L, size_t n_waves);
+
 int finish_launch(rm_ctx* c, hipStream_t s);
 int time_begin(rm_ctx* c, hipStream_t s);
 int time_end(rm_ctx* c, hipStream_t s);
@@ -157,32 +172,12 @@ int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames,
     // Heaviest-tile-first dispatch order (see rm_tile_cost); pointless when nothing can be culled
     // cheaply estimated (culling off) or when the frame has fewer tiles than the chip has wave slots.
     if (c->balance && cull && L.n_rec != 0u && L.max_iter != 0u) {
-        const size_t need = (size_t)n_tiles * n_frames;
-        if (need > c->d_tiles_cap) {
-            if (c->d_cost) (void)hipFree(c->d_cost);
-            if (c->d_order) (void)hipFree(c->d_order);
-            c->d_cost = c->d_order = nullptr;
-            c->d_tiles_cap = 0;
-            HIP_TRY(c, hipMalloc(&c->d_cost, need * sizeof(uint32_t)));
-            HIP_TRY(c, hipMalloc(&c->d_order, need * sizeof(uint32_t)));
-            c->d_tiles_cap = need;
-        }
+        if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
         hipLaunchKernelGGL((rmk::rm_tile_cost<R>), grid, dim3(64), (size_t)L.n_cull * 16u, s, L, c->d_cost);
         hipLaunchKernelGGL(rmk::rm_tile_sort, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, n_tiles);
         L.order = c->d_order;
     }
-    if (c->wave_stats) {
-        const size_t need = (size_t)n_tiles * n_frames * WPT * 4u * sizeof(unsigned long long);
-        if (need > c->d_stats_bytes) {
-            if (c->d_stats) (void)hipFree(c->d_stats);
-            c->d_stats = nullptr;
-            c->d_stats_bytes = 0;
-            HIP_TRY(c, hipMalloc(&c->d_stats, need));
-            c->d_stats_bytes = need;
-        }
-        c->stats_valid_bytes = need;
-        L.stats = c->d_stats;
-    }
+    if (int rc = ensure_stats(c, L, (size_t)n_tiles * n_frames * WPT)) return rc;
     if (int rc = time_begin(c, s)) return rc;
     if (lds)
         hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgLds, true, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
@@ -222,23 +217,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
                          (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
-    const size_t need = (size_t)n_tiles * n_frames;
-    if (need > c->d_tiles_cap) {
-        if (c->d_cost) (void)hipFree(c->d_cost);
-        if (c->d_order) (void)hipFree(c->d_order);
-        c->d_cost = c->d_order = nullptr;
-        c->d_tiles_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_cost, need * sizeof(uint32_t)));
-        HIP_TRY(c, hipMalloc(&c->d_order, need * sizeof(uint32_t)));
-        c->d_tiles_cap = need;
-    }
-    if (n_frames > c->d_counters_cap) {
-        if (c->d_counters) (void)hipFree(c->d_counters);
-        c->d_counters = nullptr;
-        c->d_counters_cap = 0;
-        HIP_TRY(c, hipMalloc(&c->d_counters, (size_t)n_frames * 2u * sizeof(uint32_t)));
-        c->d_counters_cap = n_frames;
-    }
+    if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
+    if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 2u)) return rc;
     hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames), dim3(256),
                        (size_t)(1024u + 4u) * 4u + cull_bytes, s, L, c->d_cost, n_tiles);
     hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, c->d_counters,
@@ -249,18 +229,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (per_cu < 1u) per_cu = 1u;
     const uint32_t n_wg = std::min<uint32_t>(n_tiles, (uint32_t)std::max(1, c->cu_count) * per_cu);
     dim3 grid(n_wg, 1, n_frames);
-    if (c->wave_stats) {
-        const size_t sneed = (size_t)n_wg * n_frames * WPT * 4u * sizeof(unsigned long long);
-        if (sneed > c->d_stats_bytes) {
-            if (c->d_stats) (void)hipFree(c->d_stats);
-            c->d_stats = nullptr;
-            c->d_stats_bytes = 0;
-            HIP_TRY(c, hipMalloc(&c->d_stats, sneed));
-            c->d_stats_bytes = sneed;
-        }
-        c->stats_valid_bytes = sneed;
-        L.stats = c->d_stats;
-    }
+    if (int rc = ensure_stats(c, L, (size_t)n_wg * n_frames * WPT)) return rc;
     if (int rc = time_begin(c, s)) return rc;
     // reference-only programs run the lean interpreter; extension node types select the wider one
     const bool ext = c->decoded.has_extensions;
@@ -367,6 +336,22 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     }
     if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
+}
+
+int ensure_tile_buffers(rm_ctx* c, size_t n_tiles_total) {
+    size_t cap = c->d_tiles_cap;
+    if (int rc = grow_device(c, &c->d_cost, &cap, n_tiles_total)) return rc;
+    if (int rc = grow_device(c, &c->d_order, &c->d_tiles_cap, n_tiles_total)) return rc;
+    return RM_OK;
+}
+int ensure_stats(rm_ctx* c, RmLaunch& L, size_t n_waves) {
+    if (!c->wave_stats) return RM_OK;
+    size_t cap = c->d_stats_bytes / sizeof(unsigned long long);  // in u64 elements
+    if (int rc = grow_device(c, &c->d_stats, &cap, n_waves * 4u)) return rc;
+    c->d_stats_bytes = cap * sizeof(unsigned long long);
+    c->stats_valid_bytes = n_waves * 4u * sizeof(unsigned long long);
+    L.stats = c->d_stats;
+    return RM_OK;
 }
 
 int time_begin(rm_ctx* c, hipStream_t s) {
