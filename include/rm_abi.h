@@ -22,7 +22,9 @@
  * `int` returns RM_OK (0) or a negative rm_status; nothing throws or unwinds across the
  * ABI.  The caller owns every pointer it passes in; the library copies before returning.
  * An rm_ctx is bound to one GPU and is externally synchronised (one thread at a time);
- * different contexts may be used concurrently from different threads/processes.
+ * different contexts may be used concurrently from different threads/processes.  Asynchronous
+ * (device-destination) draws of ONE context share its scratch buffers: issue them on one stream,
+ * or wait for a draw before issuing the next on another stream.
  *
  * Output image: RGBA32F, 16 bytes per pixel, row-major, top row first (framebuffer
  * orientation); pixel (px,py) has pt_screen = (-1 + 2(px+.5)/W, 1 - 2(py+.5)/H), the

@@ -168,6 +168,14 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
 #pragma unroll
     for (int k = 0; k < R; k++) acc[k] = 0.0f;
     uint32_t sp = 0, c = 0;
+#ifdef RM_SIMPLE_LOOP
+    for (; c < n_rec; c++) {
+        uint32_t op0;
+        float p0[7];
+        prog.load(c, op0, p0);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny);
+    }
+#else
     uint32_t op0, op1;
     float p0[7], p1[7];
     prog.load(0u, op0, p0);
@@ -179,6 +187,7 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
         exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny);
         if (++c == n_rec) break;
     }
+#endif
 #pragma unroll
     for (int k = 0; k < R; k++) out[k] = acc[k];
 }
