@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The native libraries are git-ignored build products: build them if a fresh checkout lacks them
+    # (hipcc cross-compiles gfx950 without a GPU).  Up-to-date libraries are left alone.
+    from ray_marching_amd import build
+    if not (os.path.exists(build.HIP_SO) and os.path.exists(build.HOST_SO)):
+        build.build_all()
 
 
 @pytest.fixture(scope="session")
