@@ -35,6 +35,10 @@ def parse():
     p.add_argument("--kernel", type=int, default=0, help="rm_kernel enum (0 = default tuned kernel)")
     p.add_argument("--refill-min", type=int, default=0, help="raypool refill threshold (0 = library default)")
     p.add_argument("--waves-per-tile", type=int, default=0, help="v3 kernels: 1/2/4/8 waves share a tile (0 = default)")
+    p.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],
+                   help="structure specialisation of the march kernel (hipRTC): 0 interpreter kernel only, 1 compile in the "
+                        "background, 2 compile when the scene is uploaded (default: the scene is static, so the one-off "
+                        "compilation happens before the warm-up, like the reference's own shader compilation)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
     p.add_argument("--camera", choices=["still", "orbit"], default="still")
@@ -110,6 +114,7 @@ def main():
     W, H = args.width, args.height
     res = renderer.RayMarchingResources(local_rank)
     res.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
+    res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
     if args.refill_min:
         res.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
     if args.waves_per_tile:
@@ -179,6 +184,8 @@ def main():
     elapsed = t1 - t0
     draw_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)    # all launches of a draw
     kernel_ms = res.info(_ffi.RM_INFO_KERNEL_MS)                              # the dominant (march) kernel alone
+    specialized = bool(res.info(_ffi.RM_INFO_SPECIALIZED))                    # what the LAST timed launch ran
+    jit_ms = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
     res.set_option(_ffi.RM_OPT_TIMING, 0)
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms, draw_ms], dtype=torch.float64,
@@ -208,12 +215,14 @@ def main():
             "config": {"workload": "%dx%d, %s (%d commands / %d words), %d max steps, 16 rays/px, RGBA32F out"
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
                        "camera": args.camera, "kernel": args.kernel,
+                       "specialized_kernel": specialized, "jit_compile_ms": jit_ms,
                        "sharding": ("one frame tiled over ranks in interleaved 16-row strips%s, no collective"
                                     % (" + host gather" if args.gather else "")) if tile
                        else ("frames over ranks, no collective" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "rm_render_v5 = the dominant (march) kernel: kernel_ms; `achieved` divides the frame's "
+                         "kernel": ("rm_render_v5_spec (hipRTC-compiled for this scene's structure)" if specialized else "rm_render_v5")
+                                   + " = the dominant (march) kernel: kernel_ms; `achieved` divides the frame's "
                                    "bytes by draw_ms, the draw's three launches (pre-pass, sort, march)",
                          "kernel_ms": kernel_ms, "draw_ms": draw_ms,
                          "note": "algorithmic bytes = 16 B/pixel (one RGBA32F store); the kernel is FP32-VALU "

@@ -33,7 +33,10 @@
 #ifndef RM_ABI_H
 #define RM_ABI_H
 
+#if !defined(__HIPCC_RTC__) /* hipRTC provides the fixed-width types itself */
+#include <stddef.h>
 #include <stdint.h>
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -97,7 +100,13 @@ enum rm_option {
     RM_OPT_CULL = 4,       /* v3 kernels: 1 (default) = shade rays that provably miss the scene without marching */
     RM_OPT_BALANCE = 5,    /* v3 kernels: 1 (default) = cost pre-pass + heaviest-tile-first dispatch order */
     RM_OPT_WAVES_PER_TILE = 7, /* v3 kernels: waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
-    RM_OPT_WAVE_STATS = 6  /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
+    RM_OPT_WAVE_STATS = 6, /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
+    RM_OPT_SPECIALIZE = 8  /* structure specialisation of the default (v5) march kernel: the command sequence is compiled
+                              into straight-line code with hipRTC, once per program STRUCTURE (parameters stay data);
+                              results are bit-identical to the interpreter kernel.
+                              0 = never; 1 (default) = compile on a background thread, draw with the interpreter kernel
+                              until the compiled one is ready; 2 = the first draw of a new structure waits for the compiler.
+                              Without libhiprtc, or if compilation fails, the interpreter kernel keeps drawing. */
 };
 enum rm_kernel {
     RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */
@@ -120,7 +129,11 @@ enum rm_info {
     RM_INFO_PROGRAM_WORDS = 2,
     RM_INFO_PROGRAM_DEPTH = 3,   /* maximum value-stack depth of the current program */
     RM_INFO_DEVICE = 4,
-    RM_INFO_CU_COUNT = 5
+    RM_INFO_CU_COUNT = 5,
+    RM_INFO_SPECIALIZED = 6,     /* 1 if the last march launch ran a structure-specialised kernel, else 0 */
+    RM_INFO_JIT_STATE = 7,       /* specialisation of the current program: 0 none requested, 1 compiling, 2 ready, 3 failed
+                                    (rm_jit_log has the reason) */
+    RM_INFO_JIT_COMPILE_MS = 8   /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
 };
 
 int rm_abi_version(void);
@@ -199,6 +212,17 @@ int rm_selftest_ops(rm_ctx* ctx, const float* a, const float* b, float* out, uin
 int rm_read_wave_stats(rm_ctx* ctx, void* dst, uint64_t cap_bytes, uint64_t* out_bytes);
 
 /* Message for the last error on this context (ctx may be NULL: last rm_create error). */
+/* Structure specialisation (RM_OPT_SPECIALIZE), inspection entry points.  None of them needs a GPU.
+ * rm_jit_source: the HIP source generated for a command stream (NUL-terminated, truncated to cap; *needed = full length + 1).
+ * rm_jit_compile: generate and compile it for gfx950 with hipRTC; RM_ERR_DEVICE if libhiprtc is missing or the
+ *                 compilation fails (log receives the reason).  Nothing is cached or loaded.
+ * rm_jit_log: compiler / loader messages for the context's current program (empty string if none). */
+int rm_jit_source(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, char* buf, size_t cap,
+                  size_t* needed);
+int rm_jit_compile(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, double* compile_ms,
+                   size_t* code_bytes, char* log, size_t log_cap);
+int rm_jit_log(rm_ctx* ctx, char* buf, size_t cap);
+
 const char* rm_last_error(rm_ctx* ctx);
 const char* rm_status_string(int status);
 

@@ -31,14 +31,14 @@ RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVIC
 RM_ERR_NO_DEVICE, RM_ERR_ARG = -10, -11
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
 RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
-RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE = 5, 6, 7
+RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE = 5, 6, 7, 8
 RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0, 1, 2, 3
 RM_KERNEL_MULTI1, RM_KERNEL_MULTI1_LDS, RM_KERNEL_MULTI2, RM_KERNEL_MULTI2_LDS = 4, 5, 6, 7
 RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
 RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
 RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
-RM_INFO_DEVICE, RM_INFO_CU_COUNT = 4, 5
+RM_INFO_DEVICE, RM_INFO_CU_COUNT, RM_INFO_SPECIALIZED, RM_INFO_JIT_STATE, RM_INFO_JIT_COMPILE_MS = 4, 5, 6, 7, 8
 
 _hip = None
 _host = None
@@ -59,9 +59,14 @@ def _preload_hip_runtime():
     except (ImportError, ValueError):
         spec = None
     if spec and spec.submodule_search_locations:
-        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        cand = os.path.join(libdir, "libamdhip64.so")
         if os.path.exists(cand):
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            # ... and the run-time compiler of the same ROCm release (csrc/rm_jit.h asks for it by SONAME)
+            rtc = os.path.join(libdir, "libhiprtc.so")
+            if os.path.exists(rtc) and not os.environ.get("RM_HIPRTC_SO"):
+                C.CDLL(rtc, mode=C.RTLD_GLOBAL)
 
 
 def hip_lib():
@@ -101,6 +106,14 @@ def hip_lib():
         L.rm_selftest_ops.restype = C.c_int
         L.rm_read_wave_stats.argtypes = [vp, vp, u64, C.POINTER(u64)]
         L.rm_read_wave_stats.restype = C.c_int
+        sz = C.c_size_t
+        L.rm_jit_source.argtypes = [u32, C.POINTER(u32), u32, C.c_int, C.c_char_p, sz, C.POINTER(sz)]
+        L.rm_jit_source.restype = C.c_int
+        L.rm_jit_compile.argtypes = [u32, C.POINTER(u32), u32, C.c_int, C.POINTER(C.c_double), C.POINTER(sz),
+                                     C.c_char_p, sz]
+        L.rm_jit_compile.restype = C.c_int
+        L.rm_jit_log.argtypes = [vp, C.c_char_p, sz]
+        L.rm_jit_log.restype = C.c_int
         L.rm_last_error.argtypes = [vp]
         L.rm_last_error.restype = C.c_char_p
         L.rm_status_string.argtypes = [C.c_int]

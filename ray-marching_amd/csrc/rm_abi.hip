@@ -13,6 +13,7 @@
 
 #include "rm_abi.h"
 #include "rm_decode.h"
+#include "rm_jit.h"
 #include "rm_device.h"
 #include "rm_kernels.h"
 #include "rm_kernel_multi.h"
@@ -73,6 +74,14 @@ struct rm_ctx {
     size_t d_tiles_cap = 0;
     bool timing = false;
     double last_kernel_ms = 0.0;
+    // structure specialisation (rm_jit.h): 0 off, 1 compile in the background and switch over when
+    // ready, 2 wait for the compiler at the first draw of a new structure
+    int specialize = 1;
+    uint64_t prog_gen = 0;  // bumped whenever the decoded program changes
+    std::shared_ptr<rmjit::Entry> spec;
+    uint64_t spec_gen = ~0ull;
+    int spec_wpt = 0;
+    bool last_specialized = false;  // the last march launch ran a specialised kernel
     std::string err;
 };
 
@@ -128,8 +137,44 @@ int ensure_program(rm_ctx* c) {
         }
     }
     c->decoded = std::move(d);
+    c->prog_gen++;
     c->cmd_status = RM_OK;
     return RM_OK;
+}
+
+// The specialised march kernel for the current program and WPT waves per tile on this device, or
+// nullptr: specialisation off, not possible, still compiling (mode 1) or failed -- the caller then
+// launches the interpreter kernel.  Never an error.
+hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
+    if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
+    if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
+        // same structure as before (parameters moved): the key lookup finds the same entry
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt);
+        c->spec_gen = c->prog_gen;
+        c->spec_wpt = wpt;
+    }
+    rmjit::Entry* e = c->spec.get();
+    if (!e) return nullptr;
+    const rmjit::Entry::State st = c->specialize >= 2 ? e->wait() : e->peek();
+    if (st != rmjit::Entry::READY) return nullptr;
+    std::lock_guard<std::mutex> lk(e->m);
+    rmjit::Entry::Loaded& l = e->loaded[c->device];
+    if (!l.function && !l.module && !e->code.empty()) {
+        hipModule_t mod = nullptr;
+        hipFunction_t fn = nullptr;
+        if (hipModuleLoadData(&mod, e->code.data()) == hipSuccess &&
+            hipModuleGetFunction(&fn, mod, rmjit::kernel_name()) == hipSuccess) {
+            l.module = mod;
+            l.function = fn;
+            e->unload = [](void* m) { (void)hipModuleUnload(static_cast<hipModule_t>(m)); };
+        } else {
+            (void)hipGetLastError();
+            if (mod) (void)hipModuleUnload(mod);
+            e->log += "\nloading the compiled module failed";
+            e->code.clear();  // do not try again
+        }
+    }
+    return static_cast<hipFunction_t>(l.function);
 }
 
 // Device scratch that only ever grows (allocated outside of any timed or captured region the first
@@ -212,6 +257,9 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
     if (!cull) L.n_cone = L.n_slab = 0u;
     const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;
+    // structure-specialised kernel (values live in registers: no LDS spill stack)
+    hipFunction_t spec_fn = lds ? specialised_kernel(c, WPT) : nullptr;
+    if (spec_fn) L.spill_depth = 0u;
     const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
@@ -233,7 +281,13 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (int rc = time_begin(c, s)) return rc;
     // reference-only programs run the lean interpreter; extension node types select the wider one
     const bool ext = c->decoded.has_extensions;
-    if (lds && !ext)
+    c->last_specialized = spec_fn != nullptr;
+    if (spec_fn) {
+        uint32_t n_tiles_arg = n_tiles, refill = c->refill_min_v5;
+        void* args[] = {&L, &work, &n_tiles_arg, &refill};
+        hipError_t e = hipModuleLaunchKernel(spec_fn, grid.x, grid.y, grid.z, 64u * WPT, 1, 1, (unsigned)shmem, s, args, nullptr);
+        if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "launch of the specialised kernel failed: %s", hipGetErrorString(e));
+    } else if (lds && !ext)
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     else if (lds)
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
@@ -652,6 +706,10 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
     case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
+    case RM_OPT_SPECIALIZE:
+        if (value < 0 || value > 2) return fail(c, RM_ERR_ARG, "RM_OPT_SPECIALIZE: %lld is not 0, 1 or 2", (long long)value);
+        c->specialize = (int)value;
+        return RM_OK;
     case RM_OPT_WAVES_PER_TILE:
         if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RM_ERR_ARG, "waves_per_tile must be 1, 2, 4 or 8");
         c->waves_per_tile = (int)value;
@@ -684,6 +742,17 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     }
     case RM_INFO_DEVICE: *out = c->device; return RM_OK;
     case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
+    case RM_INFO_SPECIALIZED: *out = c->last_specialized ? 1.0 : 0.0; return RM_OK;
+    case RM_INFO_JIT_STATE:
+    case RM_INFO_JIT_COMPILE_MS: {
+        *out = 0.0;
+        if (c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty) {
+            std::lock_guard<std::mutex> lk(c->spec->m);
+            if (key == RM_INFO_JIT_STATE) *out = 1.0 + (double)c->spec->state;
+            else *out = c->spec->compile_ms;
+        }
+        return RM_OK;
+    }
     case RM_INFO_PROGRAM_COMMANDS:
     case RM_INFO_PROGRAM_WORDS:
     case RM_INFO_PROGRAM_DEPTH: {
@@ -771,6 +840,58 @@ RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, d
     (void)hipFree(buf);
     if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "write-bandwidth calibration failed: %s", hipGetErrorString(e));
     *out_gbps = (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return RM_OK;
+}
+
+namespace {
+int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int wpt, std::string* src) {
+    if (wpt != 1 && wpt != 2 && wpt != 4 && wpt != 8) return RM_ERR_ARG;
+    RmDecoded d;
+    int rc = rm_decode_program(cmd_count, words, n_words, &d);
+    if (rc != RM_OK) return rc;
+    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, src)) return RM_ERR_ARG;
+    return RM_OK;
+}
+void copy_out(const std::string& s, char* buf, size_t cap) {
+    if (!buf || !cap) return;
+    const size_t n = s.size() < cap - 1 ? s.size() : cap - 1;
+    std::memcpy(buf, s.data(), n);
+    buf[n] = 0;
+}
+}  // namespace
+
+RM_EXPORT int rm_jit_source(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, char* buf,
+                            size_t cap, size_t* needed) {
+    std::string src;
+    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile, &src);
+    if (rc != RM_OK) return rc;
+    if (needed) *needed = src.size() + 1;
+    copy_out(src, buf, cap);
+    return RM_OK;
+}
+
+RM_EXPORT int rm_jit_compile(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile,
+                             double* compile_ms, size_t* code_bytes, char* log, size_t log_cap) {
+    std::string src, msg;
+    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile, &src);
+    if (rc != RM_OK) return rc;
+    std::vector<char> code;
+    double ms = 0.0;
+    const bool ok = rmjit::compile(src, &code, &msg, &ms);
+    if (compile_ms) *compile_ms = ms;
+    if (code_bytes) *code_bytes = code.size();
+    copy_out(msg, log, log_cap);
+    return ok ? RM_OK : RM_ERR_DEVICE;
+}
+
+RM_EXPORT int rm_jit_log(rm_ctx* c, char* buf, size_t cap) {
+    if (!c) return RM_ERR_NULL;
+    std::string msg;
+    if (c->spec) {
+        std::lock_guard<std::mutex> lk(c->spec->m);
+        msg = c->spec->log;
+    }
+    copy_out(msg, buf, cap);
     return RM_OK;
 }
 

@@ -1,6 +1,8 @@
 // rm_device.h -- structures shared by the host side of librm_hip.so and its kernels.
 #pragma once
+#if !defined(__HIPCC_RTC__)
 #include <stdint.h>
+#endif
 
 #include "rm_abi.h"
 

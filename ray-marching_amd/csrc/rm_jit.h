@@ -1,0 +1,348 @@
+// rm_jit.h -- structure specialisation of the march kernel with hipRTC.  Host only.
+//
+// The reference evaluates the scene with a stack machine that re-decodes the same command
+// sequence at every march step of every ray (ray_marching.wgsl:187-203: a loop over cmd_count with
+// a switch per command).  A scene's STRUCTURE (which node types, in which order) changes only when
+// the application edits the CSG tree (csg/builder.rs:26-62 is re-run); its PARAMETERS (centres,
+// radii) may change every frame.  This file turns the structure into straight-line device code:
+// one call per leaf with its parameters read from the LDS copy of the decoded program at constant
+// offsets, operands held in registers instead of the LDS spill stack, no opcode decode, no loop.
+// The arithmetic applied to every value is the interpreter's, operation for operation (the same
+// sdf_*_t / vmin / vmax_negb functions are called), so the result is bit-identical -- only the
+// bookkeeping around it disappears.  Parameters are NOT baked in: an animation that moves
+// primitives keeps its compiled kernel.
+//
+// The generated translation unit includes the library's own kernel headers (embedded as strings by
+// build.py -> generated/rm_jit_sources.inc), defines rmk::map_scene_spec<FAST>() and instantiates
+// rm_render_v5_body<..., SPEC = true> behind an extern "C" kernel.  It is compiled for gfx950 by
+// libhiprtc (dlopen'ed: the library has no link-time dependency on it) on a worker thread and
+// cached per (structure, waves per tile).  Everything falls back to the interpreter kernel:
+// hipRTC missing, a compile error, an empty or very long program.
+#pragma once
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rm_device.h"
+
+namespace rmjit {
+
+#include "generated/rm_jit_sources.inc"  // kHeaderNames[], kHeaderSources[], kNumHeaders
+
+constexpr uint32_t kMaxRecords = 255u;  // the reference's 1024-byte command buffer holds at most 255 words
+
+// ---- hipRTC, loaded on first use -----------------------------------------------------------------
+struct Rtc {
+    typedef struct _hiprtcProgram* Program;
+    int (*CreateProgram)(Program*, const char*, const char*, int, const char* const*, const char* const*) = nullptr;
+    int (*CompileProgram)(Program, int, const char* const*) = nullptr;
+    int (*GetProgramLogSize)(Program, size_t*) = nullptr;
+    int (*GetProgramLog)(Program, char*) = nullptr;
+    int (*GetCodeSize)(Program, size_t*) = nullptr;
+    int (*GetCode)(Program, char*) = nullptr;
+    int (*DestroyProgram)(Program*) = nullptr;
+    void* handle = nullptr;
+    std::string error;
+
+    static Rtc& get() {
+        static Rtc r;
+        static std::once_flag once;
+        std::call_once(once, [] { r.load(); });
+        return r;
+    }
+    bool ok() const { return handle != nullptr; }
+
+private:
+    void load() {
+        // By SONAME first: a process that already holds a hipRTC (PyTorch bundles one next to its own
+        // libamdhip64 and comgr) keeps using that one; otherwise the ROCm installation on this library's
+        // RUNPATH.  Mixing the run-time compiler of one ROCm release with the comgr of another is avoided.
+        const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so"};
+        if (const char* env = std::getenv("RM_HIPRTC_SO")) handle = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+        for (size_t i = 0; !handle && i < sizeof names / sizeof *names; i++) handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!handle) {
+            const char* e = dlerror();
+            error = std::string("libhiprtc.so could not be loaded: ") + (e ? e : "?");
+            return;
+        }
+        bool all = true;
+        auto sym = [&](const char* n) {
+            void* p = dlsym(handle, n);
+            if (!p) { all = false; error = std::string("libhiprtc.so lacks ") + n; }
+            return p;
+        };
+        CreateProgram = reinterpret_cast<decltype(CreateProgram)>(sym("hiprtcCreateProgram"));
+        CompileProgram = reinterpret_cast<decltype(CompileProgram)>(sym("hiprtcCompileProgram"));
+        GetProgramLogSize = reinterpret_cast<decltype(GetProgramLogSize)>(sym("hiprtcGetProgramLogSize"));
+        GetProgramLog = reinterpret_cast<decltype(GetProgramLog)>(sym("hiprtcGetProgramLog"));
+        GetCodeSize = reinterpret_cast<decltype(GetCodeSize)>(sym("hiprtcGetCodeSize"));
+        GetCode = reinterpret_cast<decltype(GetCode)>(sym("hiprtcGetCode"));
+        DestroyProgram = reinterpret_cast<decltype(DestroyProgram)>(sym("hiprtcDestroyProgram"));
+        if (!all) handle = nullptr;  // the library stays mapped; it is simply not used
+    }
+};
+
+// ---- source generation ---------------------------------------------------------------------------
+// The structure of a decoded program: one character pair per record.  Two programs with the same
+// key run the same generated code (their parameters differ, and those stay in LDS).
+inline std::string structure_key(const std::vector<RmRecord>& rec) {
+    std::string k;
+    k.reserve(rec.size() * 2);
+    for (const RmRecord& r : rec) {
+        k.push_back("PSBCL???"[RM_OP_KIND(r.op)]);
+        k.push_back("pusix???"[RM_OP_MODE(r.op)]);
+    }
+    return k;
+}
+
+inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty() && rec.size() <= kMaxRecords; }
+
+// Straight-line map_scene for `rec`, mirroring exec_command (rm_kernel_multi.h) record by record
+// with the value stack resolved at generation time: the accumulator and every spilled value become
+// named values.  Returns false if the records do not form a valid program (cannot happen for the
+// output of rm_decode_program).
+inline bool generate_map_scene(const std::vector<RmRecord>& rec, std::string* out) {
+    std::string s;
+    char line[256];
+    s += "namespace rmk {\n";
+    s += "template <bool FAST>\n";
+    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, uint32_t& tiny) {\n";
+    std::vector<int> stack;  // value numbers; back() is the accumulator
+    int nv = 0;
+    for (size_t i = 0; i < rec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        const unsigned off = (unsigned)i * 8u + 1u;  // first parameter of record i, in dwords
+        int a = -1, b = -1;
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+            b = stack.back(); stack.pop_back();
+            a = stack.back(); stack.pop_back();
+        } else {
+            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
+                           : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
+            if (!fn) return false;
+            b = nv++;
+            if (kind == RM_KIND_PLANE)
+                std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, qx, qy, qz);\n", b, fn, off);
+            else
+                std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, qx, qy, qz, tiny);\n", b, fn, off);
+            s += line;
+            if (mode == RM_MODE_PUSH) { stack.push_back(b); continue; }
+            if (stack.empty()) return false;
+            a = stack.back(); stack.pop_back();
+        }
+        const int w = nv++;
+        switch (mode) {
+        case RM_MODE_UNION: std::snprintf(line, sizeof line, "    const float v%d = vmin(v%d, v%d);\n", w, a, b); break;
+        case RM_MODE_SUB: std::snprintf(line, sizeof line, "    const float v%d = vmax_negb(v%d, v%d);\n", w, a, b); break;
+        case RM_MODE_INTER: std::snprintf(line, sizeof line, "    const float v%d = fmax_(v%d, v%d);\n", w, a, b); break;
+        case RM_MODE_SMOOTH:
+            if (kind != RM_KIND_POP) return false;  // the decoder never fuses an operator that has a parameter
+            std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d);\n", w, off, a, b);
+            break;
+        default: return false;
+        }
+        s += line;
+        stack.push_back(w);
+    }
+    if (stack.empty()) return false;
+    std::snprintf(line, sizeof line, "    return v%d;\n}\n}  // namespace rmk\n", stack.back());
+    s += line;
+    *out = std::move(s);
+    return true;
+}
+
+inline const char* kernel_name() { return "rm_render_v5_spec"; }
+
+inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, std::string* out) {
+    std::string body;
+    if (!generate_map_scene(rec, &body)) return false;
+    std::string s;
+    // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
+    s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
+         "typedef unsigned long long rm_rtc_u64;\ntypedef int rm_rtc_i32;\ntypedef long long rm_rtc_i64;\n"
+         "#define uint8_t rm_rtc_u8\n#define uint16_t rm_rtc_u16\n#define uint32_t rm_rtc_u32\n#define uint64_t rm_rtc_u64\n"
+         "#define int32_t rm_rtc_i32\n#define int64_t rm_rtc_i64\n";
+    s += "#define RM_JIT_TU 1\n";
+    s += "#include \"rm_kernel_v5.h\"\n";
+    s += body;
+    char line[512];
+    std::snprintf(line, sizeof line,
+                  "extern \"C\" __global__ __launch_bounds__(%d) void %s(RmLaunch L, rmk::V5Work work, uint32_t n_tiles, "
+                  "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true>(L, work, n_tiles, refill_min);\n}\n",
+                  64 * wpt, kernel_name(), wpt);
+    s += line;
+    *out = std::move(s);
+    return true;
+}
+
+// Compile `src` for gfx950.  No HIP runtime call is made: this runs on worker threads and on
+// machines without a GPU (the build check).
+inline bool compile(const std::string& src, std::vector<char>* code, std::string* log, double* ms) {
+    Rtc& rtc = Rtc::get();
+    if (!rtc.ok()) { *log = rtc.error; return false; }
+    const auto t0 = std::chrono::steady_clock::now();
+    Rtc::Program prog = nullptr;
+    int rc = rtc.CreateProgram(&prog, src.c_str(), "rm_spec.hip", (int)kNumHeaders, kHeaderSources, kHeaderNames);
+    if (rc != 0) { *log = "hiprtcCreateProgram failed: " + std::to_string(rc); return false; }
+    // the flags of the offline build (build.py HIP_FLAGS) that affect code generation
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    rc = rtc.CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
+    size_t n = 0;
+    if (rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) {
+        log->resize(n);
+        rtc.GetProgramLog(prog, &(*log)[0]);
+    }
+    bool ok = rc == 0;
+    if (ok) {
+        n = 0;
+        ok = rtc.GetCodeSize(prog, &n) == 0 && n > 0;
+        if (ok) {
+            code->resize(n);
+            ok = rtc.GetCode(prog, code->data()) == 0;
+        }
+    } else if (log->empty()) {
+        *log = "hiprtcCompileProgram failed: " + std::to_string(rc);
+    }
+    rtc.DestroyProgram(&prog);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return ok;
+}
+
+// ---- cache ------------------------------------------------------------------------------------------
+struct Entry {
+    enum State : int { COMPILING = 0, READY = 1, FAILED = 2 };
+    std::mutex m;
+    std::condition_variable cv;
+    State state = COMPILING;
+    std::vector<char> code;  // gfx950 code object
+    std::string log;
+    double compile_ms = 0.0;
+    // Filled by the caller's (HIP) thread under `m`: device ordinal -> {hipModule_t, hipFunction_t}.
+    struct Loaded { void* module = nullptr; void* function = nullptr; };
+    std::map<int, Loaded> loaded;
+    void (*unload)(void* module) = nullptr;  // hipModuleUnload, set by whoever loads
+
+    State wait() {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return state != COMPILING; });
+        return state;
+    }
+    State peek() {
+        std::lock_guard<std::mutex> lk(m);
+        return state;
+    }
+    ~Entry() {
+        if (unload)
+            for (auto& kv : loaded)
+                if (kv.second.module) unload(kv.second.module);
+    }
+};
+
+class Cache {
+public:
+    static constexpr size_t kMaxEntries = 256;  // beyond this, entries no context holds are dropped
+
+    static Cache& get() {
+        static Cache* c = new Cache;  // never destroyed: see shutdown()
+        return *c;
+    }
+    // The entry for (rec structure, wpt); queues its compilation for the worker thread the first time.
+    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt) {
+        const std::string key = std::to_string(wpt) + ":" + structure_key(rec);
+        std::unique_lock<std::mutex> lk(m_);
+        auto it = entries_.find(key);
+        if (it != entries_.end()) return it->second;
+        if (entries_.size() >= kMaxEntries) {
+            for (auto j = entries_.begin(); j != entries_.end();)
+                j = (j->second.use_count() == 1 && j->second->peek() != Entry::COMPILING) ? entries_.erase(j) : ++j;
+        }
+        auto e = std::make_shared<Entry>();
+        entries_[key] = e;
+        Job job;
+        job.entry = e;
+        if (!generate_source(rec, wpt, &job.source)) {
+            e->state = Entry::FAILED;
+            e->log = "program structure could not be turned into code";
+            return e;
+        }
+        queue_.push_back(std::move(job));
+        if (!worker_.joinable()) {
+            worker_ = std::thread([this] { run(); });
+            std::atexit([] { Cache::get().shutdown(); });
+        }
+        lk.unlock();
+        cv_.notify_one();
+        return e;
+    }
+    size_t size() {
+        std::lock_guard<std::mutex> lk(m_);
+        return entries_.size();
+    }
+    // A process must not run its static destructors underneath a compiling thread: finish the job in
+    // flight, drop the rest.  Modules stay loaded; the HIP runtime may already be gone.
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (worker_.joinable()) worker_.join();
+    }
+
+private:
+    struct Job { std::shared_ptr<Entry> entry; std::string source; };
+    void run() {
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !queue_.empty(); });
+                if (stop_) break;
+                job = std::move(queue_.front());
+                queue_.erase(queue_.begin());
+            }
+            std::vector<char> code;
+            std::string log;
+            double ms = 0.0;
+            const bool ok = compile(job.source, &code, &log, &ms);
+            {
+                std::lock_guard<std::mutex> g(job.entry->m);
+                job.entry->code = std::move(code);
+                job.entry->log = std::move(log);
+                job.entry->compile_ms = ms;
+                job.entry->state = ok ? Entry::READY : Entry::FAILED;
+            }
+            job.entry->cv.notify_all();
+        }
+        // anything still queued will never be compiled: release the waiters
+        std::lock_guard<std::mutex> lk(m_);
+        for (Job& j : queue_) {
+            {
+                std::lock_guard<std::mutex> g(j.entry->m);
+                j.entry->state = Entry::FAILED;
+                j.entry->log = "process is shutting down";
+            }
+            j.entry->cv.notify_all();
+        }
+        queue_.clear();
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::map<std::string, std::shared_ptr<Entry>> entries_;
+    std::vector<Job> queue_;
+    std::thread worker_;
+    bool stop_ = false;
+};
+
+}  // namespace rmjit

@@ -510,6 +510,7 @@ __global__ __launch_bounds__(64) void rm_tile_cost(RmLaunch L, uint32_t* cost) {
 }
 
 // Counting sort of the tile ids of one frame (blockIdx.x = frame) by descending cost.
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(1024) void rm_tile_sort(const uint32_t* cost, uint32_t* order, uint32_t n_tiles) {
     __shared__ uint32_t hist[65], base[65];
     const uint32_t tid = threadIdx.x;
@@ -529,12 +530,14 @@ __global__ __launch_bounds__(1024) void rm_tile_sort(const uint32_t* cost, uint3
         o[pos] = i;
     }
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // Self-tests of the arithmetic building blocks (diagnostics, rm_selftest_* in the ABI).
 // ---------------------------------------------------------------------------------------------
 // Exhaustive: sqrt_rn_fast(x) == correctly rounded sqrt for EVERY binary32 x in its stated domain
 // (x == 0, x >= 2^-96, +inf, NaN), i.e. for all bit patterns in [first, first + count).
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* mismatches,
                                                                uint32_t* first_bad) {
     const uint64_t stride = (uint64_t)gridDim.x * 256u;
@@ -553,10 +556,12 @@ __global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, u
     }
     if (bad) atomicAdd(mismatches, bad);
 }
+#endif
 
 // Element-wise results of the primitives the kernels rely on, for comparison with the oracle's
 // definitions on the host: out[0..7][i] = min, max, direct v_min, direct v_max(a,-b), fast sqrt(a),
 // generic sqrt(a), a / b, (float) i32(round(a)).
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_selftest_ops_kernel(const float* a, const float* b, float* out, uint32_t n) {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
@@ -572,5 +577,6 @@ __global__ __launch_bounds__(256) void rm_selftest_ops_kernel(const float* a, co
     out[6u * n + i] = x / y;
     out[7u * n + i] = (float)__float2int_rz(__builtin_rintf(x));
 }
+#endif
 
 }  // namespace rmk

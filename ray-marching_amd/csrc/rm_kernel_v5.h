@@ -28,6 +28,42 @@
 
 namespace rmk {
 
+// Structure-specialised evaluation (rm_jit.h): when a program's command sequence has been compiled
+// into straight-line code by hipRTC, the generated translation unit defines this function and
+// instantiates the kernel body with SPEC = true; the library's own build only declares it.
+//   lp: the decoded program in LDS (RmRecord[n], 8 dwords each: parameters are read at fixed offsets)
+template <bool FAST>
+RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, uint32_t& tiny);
+// Leaves and the one operator with a parameter, as the generated code calls them: `r` points at the
+// record's parameters in LDS (wave-uniform address, constant offset: a broadcast read).
+template <bool FAST>
+RM_DEV float spec_sphere(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+    const float p[7] = {r[0], r[1], r[2], r[3], 0.0f, 0.0f, 0.0f};
+    return sdf_sphere_t<FAST>(qx, qy, qz, p, tiny);
+}
+template <bool FAST>
+RM_DEV float spec_box(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+    const float p[7] = {r[0], r[1], r[2], r[3], r[4], r[5], 0.0f};
+    return sdf_box_t<FAST>(qx, qy, qz, p, tiny);
+}
+template <bool FAST>
+RM_DEV float spec_cylinder(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+    const float p[7] = {r[0], r[1], r[2], r[3], r[4], 0.0f, 0.0f};
+    return sdf_cylinder_t<FAST>(qx, qy, qz, p, tiny);
+}
+RM_DEV float spec_plane(const float* r, float qx, float qy, float qz) {
+    return ((qx * r[0] + qy * r[1]) + qz * r[2]) + r[3];  // as exec_command
+}
+RM_DEV float spec_smooth_union(const float* r, float a, float b) {  // as exec_command, RM_MODE_SMOOTH
+    const float kk = r[0];
+    float v = fmin_(a, b);
+    if (kk > 0.0f) {
+        const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) / kk;
+        v = v - ((h * h) * kk) * 0.25f;
+    }
+    return v;
+}
+
 constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
 constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
 
@@ -136,8 +172,8 @@ struct V5Work {
 // takes the next tile of the work list with one atomic and leaves when the list is exhausted
 // (no spinning, no inter-workgroup dependency).  Tiles whose 1024 rays are all culled never reach
 // this kernel: the pre-pass writes their pixels directly.
-template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT>
-__global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
+template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT, bool SPEC>
+RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_tiles, uint32_t refill_min) {
     constexpr uint32_t POOL = 1024u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -291,9 +327,15 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
             float qx[1], qy[1], qz[1], v[1];
             qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
             uint32_t tiny = 0xFFFFFFFFu;
-            map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-            if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
-                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
+                v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), qx[0], qy[0], qz[0], tiny);
+                if (__ballot(tiny < kTinyBits) != 0ull)
+                    v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), qx[0], qy[0], qz[0], tiny);
+            } else {
+                map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+                if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
+                    map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            }
             const float sd = v[0];
             if (mode == M_MARCH) {
                 if (sd < L.min_dist) {  // wgsl:97: hit -> normal taps around pos = q
@@ -391,6 +433,11 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
     }
 }
 
+template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT>
+__global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
+    rm_render_v5_body<Prog, PROG_IN_LDS, WPT, EXT, false>(L, work, n_tiles, refill_min);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pre-pass, one workgroup per tile.  Runs the miss test on the tile's AA samples and stops as soon
 // as one ray cannot be culled: that tile goes on the work list (cost = how many of that sample's
@@ -404,6 +451,7 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 #endif
 constexpr uint32_t V5_PRE_TILES = RM_V5_PRE_TILES;  // tiles per pre-pass workgroup
 
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost, uint32_t n_tiles) {
     // 4 waves per tile: wave w tests AA samples w, w+4, w+8, w+12 (lane = pixel) and parks each
     // sample's floor colour code in LDS; thread t < 64 then sums pixel t's 16 samples in order.
@@ -472,9 +520,11 @@ __global__ __launch_bounds__(256) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost
     __syncthreads();  // codes[] and *s_surv are reused by the next tile
   }
 }
+#endif
 
 // Work list of one frame (blockIdx.x = frame): ids of the tiles with cost > 0, by descending cost
 // when `balance` is set.  Also resets the persistent kernel's cursor.
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(1024) void rm_tile_sort_v5(const uint32_t* cost, uint32_t* order, uint32_t* counters,
                                                         uint32_t n_tiles, uint32_t balance) {
     __shared__ uint32_t hist[65], base[65];
@@ -516,5 +566,6 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(const uint32_t* cost, ui
         else if (v != 0u) o[atomicAdd(&base[bucket(v)], 1u)] = i;
     }
 }
+#endif
 
 }  // namespace rmk

@@ -5,7 +5,9 @@
 // operation below is one IEEE binary32 operation in exactly the order of the arithmetic
 // contract (DESIGN.md "Arithmetic contract"), so the result is bit-identical to the oracle.
 #pragma once
+#if !defined(__HIPCC_RTC__)  // hipRTC pre-includes its own runtime header
 #include <hip/hip_runtime.h>
+#endif
 
 #include "rm_device.h"
 
@@ -155,6 +157,7 @@ RM_DEV float map_scene(const Prog& prog, uint32_t n_rec, const SpillLds& st, flo
 // Kernel v1 "pixel": one thread per pixel, 16x16-pixel workgroup (4 waves of 8x8), program
 // staged once per workgroup into LDS, AA samples and march steps in the reference's loop order.
 // =============================================================================================
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_render_pixel(RmLaunch L) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t tid = threadIdx.x;
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256) void rm_render_pixel(RmLaunch L) {
     o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
     reinterpret_cast<float4*>(out)[(size_t)ry * L.W + px] = o;
 }
+#endif
 
 // =============================================================================================
 // Kernel v2 "raypool": one wave (= one 64-thread workgroup) owns an 8x8-pixel tile and the
@@ -393,11 +397,13 @@ __global__ __launch_bounds__(64) void rm_render_raypool(RmLaunch L, uint32_t ref
 }
 
 // Stream-write calibration kernel: 16 B per lane, grid-stride.
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_fill(float4* dst, size_t n_vec, float v) {
     size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * 256u;
     float4 val = make_float4(v, v, v, v);
     for (; i < n_vec; i += stride) dst[i] = val;
 }
+#endif
 
 }  // namespace rmk

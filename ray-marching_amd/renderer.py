@@ -130,6 +130,12 @@ class RayMarchingResources:
         self._check(self._L.rm_get_info(self._h, key, C.byref(v)))
         return v.value
 
+    def jit_log(self):
+        """Compiler / loader messages of the structure specialiser for the current program ('' if none)."""
+        buf = C.create_string_buffer(1 << 16)
+        self._check(self._L.rm_jit_log(self._h, buf, len(buf)))
+        return buf.value.decode(errors="replace")
+
     def wave_stats(self, max_waves=1 << 20):
         """Diagnostics: (n_waves, 4) uint64 array recorded by the last draw with RM_OPT_WAVE_STATS."""
         buf = np.zeros((max_waves, 4), dtype=np.uint64)
@@ -178,3 +184,29 @@ def validate_program(cmd_count, words):
     ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
     rc = _ffi.hip_lib().rm_validate_program(int(cmd_count), ptr, int(w.size), C.byref(depth))
     return rc, depth.value
+
+
+def jit_source(cmd_count, words, waves_per_tile=4):
+    """rm_jit_source: the HIP source the structure specialiser generates for a command stream (no GPU needed)."""
+    w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
+    ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
+    L = _ffi.hip_lib()
+    need = C.c_size_t(0)
+    rc = L.rm_jit_source(int(cmd_count), ptr, int(w.size), int(waves_per_tile), None, 0, C.byref(need))
+    if rc != _ffi.RM_OK:
+        raise _ffi.RmError(rc, L.rm_status_string(rc).decode())
+    buf = C.create_string_buffer(need.value)
+    L.rm_jit_source(int(cmd_count), ptr, int(w.size), int(waves_per_tile), buf, need.value, None)
+    return buf.value.decode()
+
+
+def jit_compile(cmd_count, words, waves_per_tile=4):
+    """rm_jit_compile: compile the specialised kernel for gfx950 with hipRTC, without loading it (no GPU needed).
+    Returns (status, compile_ms, code_bytes, log)."""
+    w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
+    ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
+    ms, nbytes = C.c_double(0.0), C.c_size_t(0)
+    log = C.create_string_buffer(1 << 16)
+    rc = _ffi.hip_lib().rm_jit_compile(int(cmd_count), ptr, int(w.size), int(waves_per_tile), C.byref(ms),
+                                       C.byref(nbytes), log, len(log))
+    return rc, ms.value, nbytes.value, log.value.decode(errors="replace")

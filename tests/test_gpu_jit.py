@@ -1,0 +1,183 @@
+"""Structure specialisation (RM_OPT_SPECIALIZE, csrc/rm_jit.h): the hipRTC-compiled straight-line march
+kernel must be indistinguishable from the interpreter kernel and the oracle -- bit for bit -- and the
+machinery around it (cache per structure, background compilation, fallbacks) must behave as documented."""
+import time
+
+import numpy as np
+import pytest
+
+import scenes
+from ray_marching_amd import _ffi, renderer
+
+pytestmark = pytest.mark.gpu
+
+LIM = (0.01, 100.0, 96)
+
+
+@pytest.fixture(scope="module")
+def res():
+    r = renderer.RayMarchingResources(0)
+    yield r
+    r.close()
+
+
+def case(oracle, scene, W, H):
+    cc, w = oracle.serialize(*scene)
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    return cc, w, u
+
+
+def load(res, cc, w, u, mode):
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+    res.set_option(_ffi.RM_OPT_SPECIALIZE, mode)
+    res.set_limits(LIM)
+    res.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+    res.set_program(cc, w)
+
+
+ALL = dict(scenes.SCENES)
+ALL.update(scenes.EXT_SCENES)
+
+
+@pytest.mark.parametrize("name", sorted(ALL))
+def test_specialised_equals_interpreter_equals_oracle(res, oracle, name):
+    W, H = 96, 64
+    cc, w, u = case(oracle, ALL[name](), W, H)
+    res.resize_command_buffer(4096)
+    load(res, cc, w, u, 0)
+    interp = res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0
+    load(res, cc, w, u, 2)
+    spec = res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_JIT_STATE) == 2, res.jit_log()
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+    assert res.info(_ffi.RM_INFO_JIT_COMPILE_MS) > 0
+    ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
+    assert spec.tobytes() == ref.tobytes()
+    assert interp.tobytes() == ref.tobytes()
+
+
+def test_moving_parameters_keeps_the_compiled_kernel(res, oracle):
+    """The cache key is the structure: an animation that moves/resizes primitives must not recompile."""
+    W, H = 64, 48
+    nodes, root = scenes.g8()
+    cc, w, u = case(oracle, (nodes, root), W, H)
+    load(res, cc, w, u, 2)
+    res.draw(W, H)
+    ms0 = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
+    assert ms0 > 0
+    for step in range(1, 4):
+        moved = [(k, ([p[0] + 0.1 * step, p[1], p[2] - 0.05 * step] + [x * (1.0 + 0.1 * step) for x in p[3:]])
+                  if k in (0, 1) else p, l, r) for (k, p, l, r) in nodes]
+        cc2, w2 = oracle.serialize(moved, root)
+        res.set_program(cc2, w2)
+        t0 = time.perf_counter()
+        img = res.draw(W, H)
+        dt = time.perf_counter() - t0
+        assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+        assert res.info(_ffi.RM_INFO_JIT_COMPILE_MS) == ms0        # the same cache entry
+        assert dt < 0.2                                             # no compiler run in this draw
+        assert img.tobytes() == oracle.render(u, LIM, cc2, w2, W, H, threads=4).tobytes()
+
+
+def test_background_mode_draws_correctly_before_and_after_the_switch(res, oracle):
+    """Mode 1: frames keep coming from the interpreter kernel until the compiled kernel is ready."""
+    W, H = 64, 48
+    t = scenes._Tab()   # a structure no other test uses, so that this is a cache miss
+    parts = [t.sphere((0.3 * i - 1.0, 0.1 * i, 0.0), 0.4) for i in range(7)] + [t.box((0, -1, 0), (2, 0.1, 2))]
+    root = scenes._fold_left(t, parts)
+    cc, w, u = case(oracle, (t.nodes, root), W, H)
+    ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
+    load(res, cc, w, u, 1)
+    deadline = time.time() + 60.0
+    switched = False
+    n = 0
+    while time.time() < deadline:
+        img = res.draw(W, H)
+        n += 1
+        assert img.tobytes() == ref.tobytes()
+        if res.info(_ffi.RM_INFO_SPECIALIZED) == 1:
+            switched = True
+            break
+        assert res.info(_ffi.RM_INFO_JIT_STATE) in (1, 2), res.jit_log()
+        time.sleep(0.01)
+    assert switched, "compiled kernel never became ready: %s" % res.jit_log()
+    assert res.draw(W, H).tobytes() == ref.tobytes()
+
+
+def test_programs_that_are_not_specialised(res, oracle):
+    W, H = 40, 32
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    # empty program (csg_node == None)
+    load(res, 0, np.zeros(0, np.uint32), u, 2)
+    assert res.draw(W, H).tobytes() == oracle.render(u, LIM, 0, [], W, H, threads=2).tobytes()
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0 and res.info(_ffi.RM_INFO_JIT_STATE) == 0
+    # more than 255 records: the interpreter kernel
+    t = scenes._Tab()
+    parts = [t.sphere((0.02 * i - 2.6, 0.3 * ((i * 7) % 5) - 0.6, 0.1 * ((i * 3) % 7) - 0.3), 0.15) for i in range(260)]
+    root = scenes._fold_left(t, parts)
+    cc, w = oracle.serialize(t.nodes, root)
+    res.resize_command_buffer(16384)
+    load(res, cc, w, u, 2)
+    assert res.draw(W, H).tobytes() == oracle.render(u, LIM, cc, w, W, H, threads=4).tobytes()
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0
+    # the explicitly selected scalar-cache variant has no specialised form
+    cc, w, u = case(oracle, scenes.g8(), W, H)
+    load(res, cc, w, u, 2)
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5)
+    assert res.draw(W, H).tobytes() == oracle.render(u, LIM, cc, w, W, H, threads=2).tobytes()
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+    res.resize_command_buffer(1024)
+    with pytest.raises(_ffi.RmError):
+        res.set_option(_ffi.RM_OPT_SPECIALIZE, 3)
+
+
+def test_deep_and_long_programs_specialised(res, oracle):
+    """Operands live in registers in the generated code: a 32-deep stack and a 127-record program."""
+    W, H = 48, 32
+    res.resize_command_buffer(4096)
+    for scene in (scenes.right_deep(32), scenes.g64(), scenes.g32_balanced()):
+        cc, w, u = case(oracle, scene, W, H)
+        load(res, cc, w, u, 2)
+        img = res.draw(W, H)
+        assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1, res.jit_log()
+        assert img.tobytes() == oracle.render(u, LIM, cc, w, W, H, threads=4).tobytes()
+    res.resize_command_buffer(1024)
+
+
+def test_waves_per_tile_variants_and_batch(res, oracle):
+    W, H = 64, 40
+    cc, w, u = case(oracle, scenes.g32(), W, H)
+    ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
+    load(res, cc, w, u, 2)
+    for wpt in (1, 2, 8, 4):
+        res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, wpt)
+        assert res.draw(W, H).tobytes() == ref.tobytes()
+        assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+    frames = []
+    for ev in ([(1, 35.0, -25.0)], [(1, 80.0, -10.0), (2, 40.0, 0.0)], [(1, -60.0, 30.0)]):
+        uu, *_ = oracle.orbit_uniforms((float(W), float(H)), events=ev)
+        frames.append(uu)
+    batch = res.draw_batch([_ffi.Uniforms.from_buffer_copy(bytes(f)) for f in frames], W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+    for i, f in enumerate(frames):
+        assert batch[i].tobytes() == oracle.render(f, LIM, cc, w, W, H, threads=4).tobytes()
+
+
+def test_full_size_metric_config_specialised_vs_interpreter(res, oracle):
+    """BASELINE.json's metric configuration (1920x1080, 32 nodes, 256 steps): whole-frame identity of the two
+    kernels plus sampled row bands against the oracle."""
+    W, H = 1920, 1080
+    lim = (0.01, 100.0, 256)
+    cc, w, u = case(oracle, scenes.g32(), W, H)
+    load(res, cc, w, u, 0)
+    res.set_limits(lim)
+    a = res.draw(W, H)
+    load(res, cc, w, u, 2)
+    res.set_limits(lim)
+    b = res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+    assert a.tobytes() == b.tobytes()
+    for r0, rows in [(200, 3), (540, 4), (901, 3)]:
+        assert b[r0:r0 + rows].tobytes() == oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=8).tobytes()

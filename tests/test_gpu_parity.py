@@ -19,8 +19,12 @@ KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_
            _ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_MULTI2_LDS,
            _ffi.RM_KERNEL_MULTI4, _ffi.RM_KERNEL_MULTI4_LDS, _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS,
            _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]
+# pseudo variant: the default kernel with its structure-specialised (hipRTC) march kernel, compiled synchronously;
+# every explicitly named variant above runs with specialisation off, i.e. the interpreter kernels
+KERNEL_SPEC = 1000
+KERNELS.append(KERNEL_SPEC)
 KERNEL_IDS = ["pixel", "raypool", "raypool_lds", "multi1", "multi1_lds", "multi2", "multi2_lds", "multi4",
-              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds"]
+              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds", "v5_spec"]
 IDX = G.index()
 
 
@@ -41,7 +45,9 @@ def assert_same(img, ref):
 
 
 def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kernel=_ffi.RM_KERNEL_DEFAULT):
-    res.set_option(_ffi.RM_OPT_KERNEL, kernel)
+    spec = kernel in (KERNEL_SPEC, _ffi.RM_KERNEL_DEFAULT)
+    res.set_option(_ffi.RM_OPT_SPECIALIZE, 2 if spec else 0)
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5_LDS if kernel == KERNEL_SPEC else kernel)
     res.set_limits(limits)
     res.set_uniforms(u)
     res.set_program(cc, words)
@@ -51,7 +57,7 @@ def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kern
 @pytest.mark.parametrize("name", sorted(n for n in IDX if "file" in IDX[n]))
 def test_golden_fixtures(res, name, kernel):
     e = IDX[name]
-    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS):
+    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC):
         pytest.skip("only the v5 kernels render extension node types")
     u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
     setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
@@ -166,8 +172,8 @@ CULL_CAMERAS = {
 @pytest.mark.parametrize("cam", sorted(CULL_CAMERAS))
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2,
                                     _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5,
-                                    _ffi.RM_KERNEL_V5_LDS],
-                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds"])
+                                    _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
+                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds", "v5_spec"])
 def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
     """The bounding-cone shortcut must never change a pixel: culling on == culling off == oracle,
     for cameras outside, inside, far from and grazing the scene, and for several min_dist."""
@@ -215,8 +221,8 @@ def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
 
 
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL,
-                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS],
-                         ids=["default", "pixel", "raypool", "multi2", "queue_lds", "v5_lds"])
+                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
+                         ids=["default", "pixel", "raypool", "multi2", "queue_lds", "v5_lds", "v5_spec"])
 def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     """rm_draw_strips: the multi-GPU tiling partition.  Every rank's strips, scattered back,
     must reproduce the single-GPU frame byte for byte (tiling invariance)."""
@@ -239,8 +245,8 @@ def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     assert res.draw_strips(W, H, 32, 7, 8).shape[0] == 0   # more ranks than strips: empty share
 
 
-EXT_KERNELS = [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]     # older kernels: reference nodes only
-EXT_IDS = ["default", "v5", "v5_lds"]
+EXT_KERNELS = [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC]  # older kernels: reference nodes only
+EXT_IDS = ["default", "v5", "v5_lds", "v5_spec"]
 
 
 @pytest.mark.parametrize("kernel", EXT_KERNELS, ids=EXT_IDS)
