@@ -267,8 +267,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
     if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
     if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 2u)) return rc;
-    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames), dim3(256),
-                       (size_t)(1024u + 4u) * 4u + cull_bytes, s, L, c->d_cost, n_tiles);
+    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames),
+                       dim3(64u * rmk::V5_PRE_TILES), 16u + cull_bytes + (size_t)(L.n_cone + L.n_slab) * 8u, s, L, c->d_cost, n_tiles);
     hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, c->d_counters,
                        n_tiles, c->balance ? 1u : 0u);
     rmk::V5Work work{c->d_order, c->d_counters};

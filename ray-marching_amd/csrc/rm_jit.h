@@ -215,6 +215,13 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
         *log = "hiprtcCompileProgram failed: " + std::to_string(rc);
     }
     rtc.DestroyProgram(&prog);
+    if (const char* dir = std::getenv("RM_JIT_DUMP_DIR")) {  // diagnostics: keep what was compiled
+        static std::atomic<int> serial{0};
+        const std::string base = std::string(dir) + "/rm_spec_" + std::to_string(serial++);
+        if (FILE* f = std::fopen((base + ".hip").c_str(), "wb")) { std::fwrite(src.data(), 1, src.size(), f); std::fclose(f); }
+        if (ok)
+            if (FILE* f = std::fopen((base + ".co").c_str(), "wb")) { std::fwrite(code->data(), 1, code->size(), f); std::fclose(f); }
+    }
     if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return ok;
 }

@@ -230,8 +230,17 @@ RM_DEV float4 cull_entry(const RmRecord& rec, const V4& ro, float min_dist) {
     if (lim > 0.0f && lim < inf && mm < inf) s = __builtin_sqrtf(lim) * 0.999f;
     return make_float4(mx, my, mz, s);
 }
+// The shader's ray direction is the .xyz of a normalised vec4 (wgsl:62): whenever the w components of
+// pt_world and ro differ (any projection with znear != 1) it is SHORTER than 1, and the march walks the
+// half-line along d / |d|.  The miss tests are statements about that half-line, so they use the unit
+// direction; a zero or non-finite d gives NaN here and every comparison below then says "not clear".
+RM_DEV void unit_dir(float& dx, float& dy, float& dz) {
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+    dx *= inv; dy *= inv; dz *= inv;  // |error| ~1e-7, far inside the 1e-5 slack of the table entries
+}
 RM_DEV bool ray_misses_scene(const float4* cullt, uint32_t n_cull, float dx, float dy, float dz) {
     bool clear = true;  // n_cull == 0 (empty scene): every ray misses (wgsl:189-191)
+    unit_dir(dx, dy, dz);
     for (uint32_t k = 0; k < n_cull; k++) {
         const float4 e = cullt[k];  // wave-uniform address: LDS broadcast
         const float t = __builtin_fmaf(e.z, dz, __builtin_fmaf(e.y, dy, __builtin_fmaf(e.x, dx, -e.w)));

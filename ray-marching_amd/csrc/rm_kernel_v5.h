@@ -136,6 +136,7 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
 // true iff the half-line o + t d (t >= 0) provably stays clear of every primitive's margin zone.
 RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float dz) {
     bool clear = *T.veto == 0u;  // no primitives (empty scene): every ray misses (wgsl:189-191)
+    unit_dir(dx, dy, dz);        // the tests are about the half-line, whatever the length of d (see unit_dir)
     for (uint32_t k = 0; k < T.n_cone; k++) {
         const float4 a = T.cone[k];  // wave-uniform address: LDS broadcast
         const float t = __builtin_fmaf(a.z, dz, __builtin_fmaf(a.y, dy, __builtin_fmaf(a.x, dx, -a.w)));
@@ -439,86 +440,154 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 }
 
 // ---------------------------------------------------------------------------------------------
-// Pre-pass, one workgroup per tile.  Runs the miss test on the tile's AA samples and stops as soon
-// as one ray cannot be culled: that tile goes on the work list (cost = how many of that sample's
-// 64 rays survive).  If ALL 1024 rays are provable misses the tile is finished here: the 16
-// gamma-corrected floor colours of each pixel are summed in the reference's order (wgsl:44-45,
-// 68-69, 73-75), the pixel is written and the tile reports cost 0.
-// ~60 % of the tiles of the metric frame end this way and never occupy a marching workgroup.
+// Pre-pass: one WAVE per tile, lane = pixel, four tiles per workgroup.
+//
+// Each lane decides whether ALL 16 AA rays of its pixel provably miss the scene, with one test per
+// primitive instead of sixteen.  The 16 sample points are an affine 4x4 grid on the screen and
+// pt_world.xyz - ro.xyz is affine in the screen position (two mat-vecs, wgsl:56-61), so the 16 ray
+// directions lie in the convex cone spanned by the four extreme samples (i, j in {0, 3}).  With the
+// unit directions e_0..e_3 of those four, c = normalize(e_0 + .. + e_3) and rho = max |e_i - c|,
+// every sample direction e of the pixel satisfies |e - c| <= rho (the distance to a fixed point is
+// maximal at a vertex of a convex spherical polygon smaller than a hemisphere; rho < 0.05 is required,
+// which also rejects a pixel whose parallelogram contains the origin).  Then for a primitive with
+// bounding cone (m, s) -- a ray clears it iff m.e < s, see cull_build_v5 --
+//     m.e = m.c + m.(e - c) <= m.c + |m| rho,
+// so  m.c + |m| rho < s  clears the primitive for the whole pixel.  Boxes get a second chance when
+// that fails: a point P of any of the pixel's rays inside the (margin-inflated) box has |P| <= D =
+// |m| + radius, and the centre ray passes within D rho of it, so if the centre ray misses the box
+// inflated by a further D rho, every ray of the pixel misses the box.  rho carries 0.1 % + 2e-6 of
+// slack for the rounding of e_i and c.
+//
+// cost = number of pixels that are not provably clear (0..64).  A tile with cost 0 is finished
+// here: its wave sums the 16 gamma-corrected floor colours of every pixel in the reference's order
+// (wgsl:44-45, 68-69, 73-75) and writes it.  Tiles with cost > 0 go on the work list; the march
+// kernel repeats the (sharper) test per ray.  ~60 % of the tiles of the metric frame end here.
 // ---------------------------------------------------------------------------------------------
-#ifndef RM_V5_PRE_TILES
-#define RM_V5_PRE_TILES 1
-#endif
-constexpr uint32_t V5_PRE_TILES = RM_V5_PRE_TILES;  // tiles per pre-pass workgroup
+constexpr uint32_t V5_PRE_TILES = 4u;  // tiles (= waves) per pre-pass workgroup
 
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
-__global__ __launch_bounds__(256) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost, uint32_t n_tiles) {
-    // 4 waves per tile: wave w tests AA samples w, w+4, w+8, w+12 (lane = pixel) and parks each
-    // sample's floor colour code in LDS; thread t < 64 then sums pixel t's 16 samples in order.
+RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const rm_uniforms& u, const V4& ro, float sx,
+                                  float sy) {
+    float cx = 0.0f, cy = 0.0f, cz = 0.0f, ex[4], ey[4], ez[4];
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        gen_ray(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex[c], ey[c], ez[c]);
+        unit_dir(ex[c], ey[c], ez[c]);
+        cx += ex[c]; cy += ey[c]; cz += ez[c];
+    }
+    unit_dir(cx, cy, cz);
+    float rho2 = 0.0f;
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) {
+        const float ax = ex[c] - cx, ay = ey[c] - cy, az = ez[c] - cz;
+        rho2 = fmax_(rho2, __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax)));
+    }
+    const float rho = __builtin_sqrtf(rho2) * 1.001f + 2.0e-6f;
+    // NaN anywhere above (zero / non-finite directions) makes this false; v_max drops a NaN operand, so
+    // the corners are checked one by one as well
+    bool clear = *T.veto == 0u && rho < 0.05f;
+#pragma unroll
+    for (uint32_t c = 0; c < 4u; c++) clear = clear && (ex[c] - cx) * (ex[c] - cx) < 1.0f && (ey[c] - cy) * (ey[c] - cy) < 1.0f && (ez[c] - cz) * (ez[c] - cz) < 1.0f;
+    for (uint32_t k = 0; k < T.n_cone; k++) {
+        const float4 a = T.cone[k];  // wave-uniform address: LDS broadcast
+        const float t = __builtin_fmaf(aux[k].x, rho, __builtin_fmaf(a.z, cz, __builtin_fmaf(a.y, cy, a.x * cx)));
+        clear = clear && (t < a.w);  // NaN -> not clear
+        if ((k & 3u) == 3u && __ballot(clear) == 0ull) return false;
+    }
+    if (T.n_slab == 0u || __ballot(clear) == 0ull) return clear;
+    const float tiny = 1.0e-30f;
+    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(cx), tiny), cx));
+    const float iy = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(cy), tiny), cy));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(fmax_(__builtin_fabsf(cz), tiny), cz));
+    for (uint32_t k = 0; k < T.n_slab; k++) {
+        const float4 c = T.slab[3u * k + 2u];
+        const float2 x = aux[T.n_cone + k];  // (|m|, D) both rounded up
+        const float t = __builtin_fmaf(x.x, rho, __builtin_fmaf(c.z, cz, __builtin_fmaf(c.y, cy, c.x * cx)));
+        if (__ballot(clear && !(t < c.w)) == 0ull) continue;  // every still-clear pixel clears the bounding sphere
+        const float infl = x.y * rho;
+        const float4 a = T.slab[3u * k], b = T.slab[3u * k + 1u];
+        const float x1 = (a.x - infl) * ix, x2 = (b.x + infl) * ix, y1 = (a.y - infl) * iy, y2 = (b.y + infl) * iy;
+        const float z1 = (a.z - infl) * iz, z2 = (b.z + infl) * iz;
+        const float tn = fmax_(fmin_(x1, x2), fmax_(fmin_(y1, y2), fmin_(z1, z2)));
+        const float tf = fmin_(fmax_(x1, x2), fmin_(fmax_(y1, y2), fmax_(z1, z2)));
+        // infl must be a number for the comparison to mean anything (a dropped NaN would shrink the box)
+        clear = clear && infl < __uint_as_float(0x7F800000u) && !(tf >= fmax_(tn, 0.0f));
+        if (__ballot(clear) == 0ull) return false;
+    }
+    return clear;
+}
+
+__global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, uint32_t* cost, uint32_t n_tiles) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    float* codes = reinterpret_cast<float*>(smem);                  // [16][64] miss codes (see miss_code)
-    uint32_t* s_surv = smem + 1024u;                                // survivors found by any wave
-    uint32_t* s_veto = smem + 1025u;
-    float4* t_cone = reinterpret_cast<float4*>(smem + 1024u + 4u);
+    uint32_t* s_veto = smem;
+    float4* t_cone = reinterpret_cast<float4*>(smem + 4u);
     float4* t_slab = t_cone + L.n_cone;
+    float2* t_aux = reinterpret_cast<float2*>(t_slab + 3u * L.n_slab);  // [n_cone + n_slab] (|m|, |m| + bounding radius)
     const CullTables cullt{t_cone, t_slab, s_veto, L.n_cone, L.n_slab};
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     rm_uniforms u = L.u;
     if (L.frames) u = L.frames[blockIdx.z];
     float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
+    const bool tables = (L.flags & 1u) != 0u;
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();
-    if (L.flags & 1u)
-        for (uint32_t k = tid; k < L.n_rec; k += 256u) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
-    const uint32_t tiles_x = (L.W + 7u) / 8u;
-  for (uint32_t tile = blockIdx.x * V5_PRE_TILES; tile < n_tiles && tile < (blockIdx.x + 1u) * V5_PRE_TILES; tile++) {
-    if (tid == 0u) *s_surv = 0u;
+    if (tables)
+        for (uint32_t k = tid; k < L.n_rec; k += 64u * V5_PRE_TILES)
+            cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
     __syncthreads();
+    if (tables) {
+        const float up = 1.0f + 1.0e-6f;
+        for (uint32_t k = tid; k < L.n_cone + L.n_slab; k += 64u * V5_PRE_TILES) {
+            float4 m;
+            float radius = 0.0f;
+            if (k < L.n_cone) {
+                m = t_cone[k];
+            } else {
+                const uint32_t j = k - L.n_cone;
+                m = t_slab[3u * j + 2u];
+                const float4 a = t_slab[3u * j], b = t_slab[3u * j + 1u];
+                const float hx = b.x - a.x, hy = b.y - a.y, hz = b.z - a.z;  // full extents of the inflated box
+                radius = 0.5f * __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * up;
+            }
+            const float len = __builtin_sqrtf(m.x * m.x + m.y * m.y + m.z * m.z) * up;
+            t_aux[k] = make_float2(len, (len + radius) * up);
+        }
+    }
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * V5_PRE_TILES + wave;
+    if (tile >= n_tiles) return;  // whole wave; no barrier follows
+    const uint32_t tiles_x = (L.W + 7u) / 8u;
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
     const uint32_t px = tx < L.W ? tx : L.W - 1u, ry = ty < L.rows ? ty : L.rows - 1u;
     const float sx = screen_x(px, L.W), sy = screen_y(rm_global_row(L, ry), L.H);
-    const bool may_cull = (L.flags & 1u) != 0u || L.max_iter == 0u;
-    if (!may_cull) {
-        if (tid == 0u) *s_surv = 64u;
-    } else {
-        for (uint32_t s = wave; s < 16u; s += 4u) {
-            if (*reinterpret_cast<volatile uint32_t*>(s_surv) != 0u) break;  // another wave found a live ray
-            float dx, dy, dz;
-            gen_ray(u, ro, sx, sy, s >> 2, s & 3u, dx, dy, dz);
-            const bool culled = L.max_iter == 0u || ((L.flags & 1u) && ray_misses_scene_v5(cullt, dx, dy, dz));
-            const uint32_t survivors = (uint32_t)__popcll(__ballot(!culled));
-            if (survivors != 0u) {
-                if (lane == 0u) atomicMax(s_surv, survivors);
-                break;
-            }
-            codes[s * 64u + lane] = miss_code(ro, dx, dy, dz);  // wgsl:117-130
+    bool clear;
+    if (L.max_iter == 0u) clear = true;  // no march step is ever taken: every ray is a miss (wgsl:92)
+    else if (!tables) clear = false;
+    else clear = pixel_misses_scene_v5(cullt, t_aux, u, ro, sx, sy);
+    const uint32_t pending = (uint32_t)__popcll(__ballot(!clear));
+    if (lane == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = pending;  // 0 = finished here
+    if (pending != 0u) return;
+    float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+    for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
+        float dx, dy, dz;
+        gen_ray(u, ro, sx, sy, s >> 2, s & 3u, dx, dy, dz);
+        const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        if (c >= 0) {
+            const float g = 0.2f * (float)c;
+            cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
         }
+        tr += __builtin_sqrtf(cr);
+        tg += __builtin_sqrtf(cg);
+        tb += __builtin_sqrtf(cb);
     }
-    __syncthreads();
-    const uint32_t survivors = *s_surv;
-    if (survivors == 0u && tid < 64u && tx < L.W && ty < L.rows) {
-        float tr = 0.0f, tg = 0.0f, tb = 0.0f;
-#pragma unroll 4
-        for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
-            const float code = codes[s * 64u + lane];
-            float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-            if (code > -2.5f) {  // floor (wgsl:127); -3 = black
-                const float g = 0.2f * (-1.0f - code);
-                cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
-            }
-            tr += __builtin_sqrtf(cr);
-            tg += __builtin_sqrtf(cg);
-            tb += __builtin_sqrtf(cb);
-        }
+    if (tx < L.W && ty < L.rows) {
         float4 o;
         o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
         reinterpret_cast<float4*>(out)[(size_t)ty * L.W + tx] = o;
     }
-    if (tid == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = survivors;  // 0 = done, else 1..64
-    __syncthreads();  // codes[] and *s_surv are reused by the next tile
-  }
 }
 #endif
 

@@ -202,6 +202,70 @@ def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
             assert_same(bal, ref)
 
 
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
+                         ids=["multi1_lds", "queue_lds", "v5_lds", "v5_spec"])
+def test_culling_with_arbitrary_uniform_matrices(res, oracle, kernel):
+    """The uniform block is three opaque blobs to the pipeline: the miss tests must hold for ANY matrices, not
+    only the reference camera's.  wgsl:62 normalises a vec4, so whenever pt_world.w != ro.w the ray direction
+    is shorter than 1 (inv_view with a non-affine last row; projections with znear != 1); viewport_extent
+    need not match the target size (AA samples then leave their pixel); degenerate matrices give NaN rays."""
+    W, H = 72, 48
+    cc, w = oracle.serialize(*scenes.g32())
+    base, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    L = oracle.lib()
+
+    def variant(edit):
+        u = type(base).from_buffer_copy(bytes(base))
+        edit(u)
+        return u
+
+    def proj(znear):
+        def edit(u):
+            m = np.zeros(16, np.float32)
+            L.rmo_perspective_inverse(W / H, 0.7853981633974483, znear, 10000.0, m.ctypes.data_as(C.POINTER(C.c_float)))
+            for i in range(16):
+                u.inv_proj[i] = float(m[i])
+        return edit
+
+    def set_view(idx, val):
+        def edit(u):
+            u.inv_view[idx] = val
+        return edit
+
+    def extent(ex, ey):
+        def edit(u):
+            u.viewport_extent[0], u.viewport_extent[1] = ex, ey
+        return edit
+
+    def zero_proj(u):
+        for i in range(16):
+            u.inv_proj[i] = 0.0
+
+    cases = {
+        "short_dir_a2": variant(set_view(11, 2.0)),       # pt_world.w = 1 - 2: |rd| ~ 0.45, same half-lines
+        "short_dir_am": variant(set_view(11, -0.6)),
+        "row3_x": variant(set_view(3, 0.8)),               # pt_world.w varies across the screen
+        "znear_0.5": variant(proj(0.5)),
+        "znear_1.5": variant(proj(1.5)),
+        "znear_3": variant(proj(3.0)),
+        "extent_small": variant(extent(9.0, 6.0)),         # AA offsets 8x the pixel pitch
+        "extent_huge": variant(extent(1e6, 1e6)),          # all 16 samples coincide with the pixel centre
+        "extent_negative": variant(extent(-float(W), float(H))),
+        "nan_rays": variant(zero_proj),
+    }
+    for name, u in cases.items():
+        uu = _ffi.Uniforms.from_buffer_copy(bytes(u))
+        for lim in [(0.01, 100.0, 96), (0.4, 100.0, 48)]:
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=uu, limits=lim, kernel=kernel)
+            res.set_option(_ffi.RM_OPT_CULL, 0)
+            off = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_CULL, 1)
+            on = res.draw(W, H)
+            assert np.array_equal(off.view(np.uint32), ref.view(np.uint32)), (name, lim, "cull off")
+            assert np.array_equal(on.view(np.uint32), ref.view(np.uint32)), (name, lim, "cull on")
+
+
 def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
     W, H = 56, 40
     u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)

@@ -18,9 +18,11 @@ p.add_argument("--max-iter", type=int, default=256)
 p.add_argument("--no-balance", action="store_true")
 p.add_argument("--wpt", type=int, default=4)
 p.add_argument("--no-cull", action="store_true")
+p.add_argument("--specialize", type=int, default=2)
 a = p.parse_args()
 res = renderer.RayMarchingResources(0)
 res.set_option(_ffi.RM_OPT_KERNEL, a.kernel)
+res.set_option(_ffi.RM_OPT_SPECIALIZE, a.specialize)
 res.set_option(_ffi.RM_OPT_BALANCE, 0 if a.no_balance else 1)
 res.set_option(_ffi.RM_OPT_CULL, 0 if a.no_cull else 1)
 res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, a.wpt)
