@@ -39,6 +39,7 @@ def parse():
                    help="structure specialisation of the march kernel (hipRTC): 0 interpreter kernel only, 1 compile in the "
                         "background, 2 compile when the scene is uploaded (default: the scene is static, so the one-off "
                         "compilation happens before the warm-up, like the reference's own shader compilation)")
+    p.add_argument("--prune", action="store_true", help="A/B: specialised kernel with far-primitive pruning (exact; measured slower)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
     p.add_argument("--camera", choices=["still", "orbit"], default="still")
@@ -115,6 +116,8 @@ def main():
     res = renderer.RayMarchingResources(local_rank)
     res.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
     res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
+    if args.prune:
+        res.set_option(_ffi.RM_OPT_PRUNE, 1)
     if args.refill_min:
         res.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
     if args.waves_per_tile:

@@ -101,6 +101,9 @@ enum rm_option {
     RM_OPT_BALANCE = 5,    /* v3 kernels: 1 (default) = cost pre-pass + heaviest-tile-first dispatch order */
     RM_OPT_WAVES_PER_TILE = 7, /* v3 kernels: waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
     RM_OPT_WAVE_STATS = 6, /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
+    RM_OPT_PRUNE = 9,      /* specialised kernels: 1 = skip, per wave and per march step, primitives that provably cannot
+                              influence the scene value there (exact; DESIGN.md "Pruning").  Default 0: on MI355X the
+                              wave-uniform tests cost more than the skipped work saves (measured) */
     RM_OPT_SPECIALIZE = 8  /* structure specialisation of the default (v5) march kernel: the command sequence is compiled
                               into straight-line code with hipRTC, once per program STRUCTURE (parameters stay data);
                               results are bit-identical to the interpreter kernel.
@@ -217,6 +220,7 @@ int rm_read_wave_stats(rm_ctx* ctx, void* dst, uint64_t cap_bytes, uint64_t* out
  * rm_jit_compile: generate and compile it for gfx950 with hipRTC; RM_ERR_DEVICE if libhiprtc is missing or the
  *                 compilation fails (log receives the reason).  Nothing is cached or loaded.
  * rm_jit_log: compiler / loader messages for the context's current program (empty string if none). */
+#define RM_JIT_PRUNE 0x100 /* OR into waves_per_tile: generate the RM_OPT_PRUNE = 1 form of the kernel */
 int rm_jit_source(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, char* buf, size_t cap,
                   size_t* needed);
 int rm_jit_compile(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, double* compile_ms,

@@ -31,12 +31,13 @@ RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVIC
 RM_ERR_NO_DEVICE, RM_ERR_ARG = -10, -11
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
 RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
-RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE = 5, 6, 7, 8
+RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE, RM_OPT_PRUNE = 5, 6, 7, 8, 9
 RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0, 1, 2, 3
 RM_KERNEL_MULTI1, RM_KERNEL_MULTI1_LDS, RM_KERNEL_MULTI2, RM_KERNEL_MULTI2_LDS = 4, 5, 6, 7
 RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
 RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
 RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
+RM_JIT_PRUNE = 0x100
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT, RM_INFO_SPECIALIZED, RM_INFO_JIT_STATE, RM_INFO_JIT_COMPILE_MS = 4, 5, 6, 7, 8
 

@@ -77,6 +77,7 @@ struct rm_ctx {
     // structure specialisation (rm_jit.h): 0 off, 1 compile in the background and switch over when
     // ready, 2 wait for the compiler at the first draw of a new structure
     int specialize = 1;
+    bool prune = false;  // RM_OPT_PRUNE: far-primitive pruning in specialised kernels (measured slower: off)
     uint64_t prog_gen = 0;  // bumped whenever the decoded program changes
     std::shared_ptr<rmjit::Entry> spec;
     uint64_t spec_gen = ~0ull;
@@ -149,7 +150,7 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
     if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
-        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt);
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, c->prune && c->decoded.prunable);
         c->spec_gen = c->prog_gen;
         c->spec_wpt = wpt;
     }
@@ -266,10 +267,10 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
     if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
-    if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 2u)) return rc;
+    if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 4u)) return rc;
     hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames),
                        dim3(64u * rmk::V5_PRE_TILES), 16u + cull_bytes + (size_t)(L.n_cone + L.n_slab) * 8u, s, L, c->d_cost, n_tiles);
-    hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, c->d_counters,
+    hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, L, c->d_cost, c->d_order, c->d_counters,
                        n_tiles, c->balance ? 1u : 0u);
     rmk::V5Work work{c->d_order, c->d_counters};
     // persistent grid: about as many workgroups as fit the chip (LDS, 32 waves per CU), never more than tiles
@@ -347,6 +348,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.n_cone = c->decoded.n_sphere;
     L.n_slab = c->decoded.n_box;
     L.smooth_slack = (float)c->decoded.smooth_slack;
+    L.scene_scale = c->decoded.scene_scale;
     L.min_dist = c->limits.min_dist;
     L.max_dist = c->limits.max_dist;
     L.max_iter = c->limits.max_iter;
@@ -706,6 +708,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
     case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
+    case RM_OPT_PRUNE: c->prune = value != 0; c->spec_gen = ~0ull; return RM_OK;
     case RM_OPT_SPECIALIZE:
         if (value < 0 || value > 2) return fail(c, RM_ERR_ARG, "RM_OPT_SPECIALIZE: %lld is not 0, 1 or 2", (long long)value);
         c->specialize = (int)value;
@@ -844,12 +847,12 @@ RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, d
 }
 
 namespace {
-int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int wpt, std::string* src) {
+int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int wpt, bool prune, std::string* src) {
     if (wpt != 1 && wpt != 2 && wpt != 4 && wpt != 8) return RM_ERR_ARG;
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return rc;
-    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, src)) return RM_ERR_ARG;
+    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, prune && d.prunable, src)) return RM_ERR_ARG;
     return RM_OK;
 }
 void copy_out(const std::string& s, char* buf, size_t cap) {
@@ -863,7 +866,7 @@ void copy_out(const std::string& s, char* buf, size_t cap) {
 RM_EXPORT int rm_jit_source(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile, char* buf,
                             size_t cap, size_t* needed) {
     std::string src;
-    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile, &src);
+    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile & 0xFF, (waves_per_tile & RM_JIT_PRUNE) != 0, &src);
     if (rc != RM_OK) return rc;
     if (needed) *needed = src.size() + 1;
     copy_out(src, buf, cap);
@@ -873,7 +876,7 @@ RM_EXPORT int rm_jit_source(uint32_t cmd_count, const uint32_t* words, uint32_t 
 RM_EXPORT int rm_jit_compile(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int waves_per_tile,
                              double* compile_ms, size_t* code_bytes, char* log, size_t log_cap) {
     std::string src, msg;
-    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile, &src);
+    int rc = jit_decode(cmd_count, words, n_words, waves_per_tile & 0xFF, (waves_per_tile & RM_JIT_PRUNE) != 0, &src);
     if (rc != RM_OK) return rc;
     std::vector<char> code;
     double ms = 0.0;

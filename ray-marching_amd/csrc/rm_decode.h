@@ -3,6 +3,7 @@
 // sphere.rs:15-21 (5 words), box.rs:14-20 (7 words), operations/mod.rs:12-18 (1 word,
 // post-order).  Host-only, no HIP.
 #pragma once
+#include <cmath>
 #include <cstring>
 #include <vector>
 
@@ -17,6 +18,10 @@ struct RmDecoded {
     uint32_t n_plane = 0;              // unbounded primitives: they veto miss-ray culling
     bool has_extensions = false;       // uses node types the reference does not implement
     double smooth_slack = 0.0;         // sum of k/4 over SmoothUnion operators
+    // Far-primitive pruning in specialised kernels (rm_kernel_v5.h "Pruning"): allowed when every node is a
+    // 1-Lipschitz leaf or a min/max operator; scene_scale = 1 + max over primitives of |centre|_1 + |size|_1
+    bool prunable = true;
+    float scene_scale = 1.0f;
 };
 
 // Returns RM_OK or a negative rm_status.  `cap_words` is the number of u32 words that
@@ -45,6 +50,15 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             if (ptr + np > cap_words) return RM_ERR_TRUNCATED;
             std::memcpy(r.p, words + ptr, np * 4);
             ptr += np;
+            {
+                double ext = 0.0;
+                for (uint32_t k = 0; k < np; k++) ext += std::fabs((double)r.p[k]);  // NaN / inf propagate: nothing is pruned then
+                const float up = std::nextafterf((float)(1.0 + ext), INFINITY);
+                if (!(up <= d.scene_scale)) d.scene_scale = up;  // also takes a NaN
+                if (kind == RM_KIND_PLANE) d.prunable = false;   // |n| need not be 1
+                // pruning threshold of a sphere, pre-multiplied (see spec_sphere_far): radius * 1.000005, rounded up
+                if (kind == RM_KIND_SPHERE) r.p[4] = std::nextafterf((float)((double)r.p[3] * 1.000005), INFINITY);
+            }
             // slot in the kernels' per-kind miss-test tables: cones for spheres, slabs for boxes and cylinders
             const uint32_t slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : (kind == RM_KIND_PLANE ? 0u : d.n_box++);
             std::memcpy(&r.p[6], &slot, 4);
@@ -82,6 +96,7 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
                 else if (!(r.p[0] <= 0.0f)) d.smooth_slack = 1.0 / 0.0;  // NaN k: nothing can be bounded
             }
             if (op == RM_CMD_INTERSECTION || op == RM_CMD_SMOOTH_UNION) d.has_extensions = true;
+            if (op == RM_CMD_SMOOTH_UNION) d.prunable = false;  // not a lattice operator
             if (depth < 2) return RM_ERR_STACK_UNDERFLOW;
             depth--;
             spilled--;

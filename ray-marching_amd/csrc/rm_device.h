@@ -22,7 +22,7 @@
 // only the bookkeeping (where a value lives) changes.
 struct RmRecord {
     uint32_t op;  // kind | mode<<3 | spill<<6
-    float p[7];   // sphere: cx cy cz r   box: cx cy cz rx ry rz   cylinder: cx cy cz r half_h
+    float p[7];   // sphere: cx cy cz r [r * 1.000005, for specialised kernels]   box: cx cy cz rx ry rz   cylinder: cx cy cz r half_h
                   // plane: nx ny nz h    POP+SMOOTH: k            p[6] (primitives): slot in the miss-test tables
 };
 static_assert(sizeof(RmRecord) == 32, "record must be 32 bytes");
@@ -49,6 +49,7 @@ struct RmLaunch {
     uint32_t flags;            // bit 0: miss-ray culling enabled
     uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program
     float smooth_slack;        // sum of k/4 over SmoothUnion operators: how far they can lower the tree value
+    float scene_scale;         // 1 + max |centre|_1 + |size|_1 over the primitives (RmDecoded::scene_scale)
     float min_dist, max_dist;  // RayMarchLimits (wgsl:78-82)
     uint32_t max_iter;
     uint32_t W, H, row0, rows;

@@ -109,50 +109,75 @@ inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty
 
 // Straight-line map_scene for `rec`, mirroring exec_command (rm_kernel_multi.h) record by record
 // with the value stack resolved at generation time: the accumulator and every spilled value become
-// named values.  Returns false if the records do not form a valid program (cannot happen for the
-// output of rm_decode_program).
-inline bool generate_map_scene(const std::vector<RmRecord>& rec, std::string* out) {
+// named values.  With `prune`, sphere and box leaves are wrapped in the wave-uniform far test of
+// rm_kernel_v5.h ("Pruning").  Returns false if the records do not form a valid program (cannot
+// happen for the output of rm_decode_program).
+inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
     std::string s;
-    char line[256];
+    char line[512];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, uint32_t& tiny) {\n";
+    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, uint32_t& tiny) {\n";
+    if (prune) {
+        s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
+        s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test
+        s += "    const float inf = __uint_as_float(0x7F800000u);\n";
+    }
     std::vector<int> stack;  // value numbers; back() is the accumulator
     int nv = 0;
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
         const unsigned off = (unsigned)i * 8u + 1u;  // first parameter of record i, in dwords
-        int a = -1, b = -1;
+        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
         if (kind == RM_KIND_POP) {
             if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            b = stack.back(); stack.pop_back();
+            const int b = stack.back(); stack.pop_back();
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d);\n", w, off, a, b);
+            else if (op) std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, v%d);\n", w, op, a, b);
+            else return false;
+            s += line;
+            stack.push_back(w);
+            continue;
+        }
+        if (mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;  // the decoder never fuses an operator with a parameter
+        int a = -1;
+        if (mode != RM_MODE_PUSH) {
+            if (stack.empty()) return false;
             a = stack.back(); stack.pop_back();
+        }
+        const int w = nv++;  // the record's result: the leaf (PUSH) or op(acc, leaf)
+        const bool pruned = prune && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX);
+        if (pruned) {
+            // result if the leaf is far for every live lane: +inf (PUSH), acc (UNION: min(acc, +inf); SUB: max(acc, -inf));
+            // Intersection max(acc, +inf) = +inf
+            if (mode == RM_MODE_PUSH || mode == RM_MODE_INTER) std::snprintf(line, sizeof line, "    float v%d = inf;\n", w);
+            else std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
+            s += line;
+            char leaf[128];
+            if (kind == RM_KIND_SPHERE) {
+                std::snprintf(line, sizeof line, "    { const float a = spec_sphere_a(lp + %u, qx, qy, qz);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", off, off);
+                std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
+            } else {
+                std::snprintf(line, sizeof line, "    { const SpecBox b = spec_box_a(lp + %u, qx, qy, qz);\n      if (spec_any_near(live, b.a > thr2k)) ", off);
+                std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
+            }
+            s += line;
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "v%d = %s; }\n", w, leaf);
+            else std::snprintf(line, sizeof line, "v%d = %s(v%d, %s); }\n", w, op, a, leaf);
+            s += line;
         } else {
             const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
                            : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
             if (!fn) return false;
-            b = nv++;
-            if (kind == RM_KIND_PLANE)
-                std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, qx, qy, qz);\n", b, fn, off);
-            else
-                std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, qx, qy, qz, tiny);\n", b, fn, off);
+            char leaf[128];
+            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, qx, qy, qz)", fn, off);
+            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, qx, qy, qz, tiny)", fn, off);
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d = %s;\n", w, leaf);
+            else std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, %s);\n", w, op, a, leaf);
             s += line;
-            if (mode == RM_MODE_PUSH) { stack.push_back(b); continue; }
-            if (stack.empty()) return false;
-            a = stack.back(); stack.pop_back();
         }
-        const int w = nv++;
-        switch (mode) {
-        case RM_MODE_UNION: std::snprintf(line, sizeof line, "    const float v%d = vmin(v%d, v%d);\n", w, a, b); break;
-        case RM_MODE_SUB: std::snprintf(line, sizeof line, "    const float v%d = vmax_negb(v%d, v%d);\n", w, a, b); break;
-        case RM_MODE_INTER: std::snprintf(line, sizeof line, "    const float v%d = fmax_(v%d, v%d);\n", w, a, b); break;
-        case RM_MODE_SMOOTH:
-            if (kind != RM_KIND_POP) return false;  // the decoder never fuses an operator that has a parameter
-            std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d);\n", w, off, a, b);
-            break;
-        default: return false;
-        }
-        s += line;
         stack.push_back(w);
     }
     if (stack.empty()) return false;
@@ -164,9 +189,9 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, std::string* ou
 
 inline const char* kernel_name() { return "rm_render_v5_spec"; }
 
-inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, std::string* out) {
+inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prune, std::string* out) {
     std::string body;
-    if (!generate_map_scene(rec, &body)) return false;
+    if (!generate_map_scene(rec, prune, &body)) return false;
     std::string s;
     // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
     s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
@@ -265,8 +290,8 @@ public:
         return *c;
     }
     // The entry for (rec structure, wpt); queues its compilation for the worker thread the first time.
-    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt) {
-        const std::string key = std::to_string(wpt) + ":" + structure_key(rec);
+    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt, bool prune) {
+        const std::string key = std::to_string(wpt) + (prune ? "p:" : ":") + structure_key(rec);
         std::unique_lock<std::mutex> lk(m_);
         auto it = entries_.find(key);
         if (it != entries_.end()) return it->second;
@@ -278,7 +303,7 @@ public:
         entries_[key] = e;
         Job job;
         job.entry = e;
-        if (!generate_source(rec, wpt, &job.source)) {
+        if (!generate_source(rec, wpt, prune, &job.source)) {
             e->state = Entry::FAILED;
             e->log = "program structure could not be turned into code";
             return e;

@@ -32,8 +32,60 @@ namespace rmk {
 // into straight-line code by hipRTC, the generated translation unit defines this function and
 // instantiates the kernel body with SPEC = true; the library's own build only declares it.
 //   lp: the decoded program in LDS (RmRecord[n], 8 dwords each: parameters are read at fixed offsets)
+//   thr, live: far-primitive pruning, see below
 template <bool FAST>
-RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, uint32_t& tiny);
+RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, uint32_t& tiny);
+
+// ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
+// A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
+// leaf's signed value t (t = v for a leaf the tree value F grows with, t = -v below an odd number of
+// subtraction right-hand sides) it is  F(t) = max(lo, min(hi, t))  for some lo <= hi, or constant.
+// Hence, if F is known to lie in [-thr, thr] and a leaf has v > thr, then t > thr >= F(t) forces
+// hi < t (resp. t < -thr <= F(t) forces lo > t): F does not depend on that leaf any more and is
+// unchanged -- bit for bit, min and max only select -- if the leaf value is replaced by +inf.  The
+// generated code then skips the leaf's square root: "acc = min(acc, +inf)" and "acc = max(acc, -inf)"
+// leave acc alone; a leaf that is pushed becomes the constant +inf.
+//
+// thr comes from the previous evaluation of the same ray.  Every node type admitted here (sphere,
+// box, capped cylinder; union, subtraction, intersection) is 1-Lipschitz in real arithmetic, so the
+// value F' at the next point q' satisfies |F' - F| <= |q' - q|; with the evaluation error E of the
+// float computation on both sides,  |F'_computed| <= |F_computed| + |q' - q| + 2E.
+//   march step (wgsl:114): |q' - q| <= |sd| (|rd| <= 1)      -> thr = 2 |sd| (1 + 1e-5) + m
+//   normal taps (wgsl:138-141): |q' - q_hit| = eps sqrt(3)    -> thr = |sd_hit| (1 + 1e-5) + 1.75e-4 + m
+//   first evaluation of a ray                                 -> thr = +inf (nothing is skipped)
+// m = 4e-6 (scene_scale + |ro|_1 + |q'|_1) covers 3E (E <= 4e-7 of that scale: a handful of binary32
+// roundings of quantities no larger than it) plus the rounding of q' itself, with 3x to spare.
+// The skip itself is a wave-uniform branch: a primitive is evaluated if ANY live lane needs it.
+//   sphere: v = sqrt(a) - r > thr  <=  a > ((thr + r) k)^2         k = 1.000005 (r k: RmRecord::p[4])
+//   box:    a = |max(q,0)|^2 > thr^2 k^2 implies a > 0, so the inner term is +0 and v = sqrt(a) > thr
+// NaN or inf anywhere (parameters, position, thr) makes the comparison false: the primitive is evaluated.
+// Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned.
+constexpr float kPruneAbs = 4.0e-6f;
+RM_DEV bool spec_any_near(bool live, bool far) { return __ballot(live && !far) != 0ull; }
+RM_DEV float spec_sphere_a(const float* r, float qx, float qy, float qz) {
+    const float dx = qx - r[0], dy = qy - r[1], dz = qz - r[2];
+    return (dx * dx + dy * dy) + dz * dz;  // the argument of sdf_sphere_t's sqrt, same operations
+}
+RM_DEV bool spec_sphere_far(const float* r, float a, float thrk) {
+    const float t = thrk + r[4];
+    return a > t * t;
+}
+template <bool FAST>
+RM_DEV float spec_sphere_v(const float* r, float a, uint32_t& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
+struct SpecBox { float qx, qy, qz, a; };
+RM_DEV SpecBox spec_box_a(const float* r, float px, float py, float pz) {
+    SpecBox b;
+    b.qx = __builtin_fabsf(px - r[0]) - r[3];
+    b.qy = __builtin_fabsf(py - r[1]) - r[4];
+    b.qz = __builtin_fabsf(pz - r[2]) - r[5];
+    const float mx = fmax_(b.qx, 0.0f), my = fmax_(b.qy, 0.0f), mz = fmax_(b.qz, 0.0f);
+    b.a = (mx * mx + my * my) + mz * mz;  // as sdf_box_t
+    return b;
+}
+template <bool FAST>
+RM_DEV float spec_box_v(const SpecBox& b, uint32_t& tiny) {
+    return sqrt_sel<FAST>(b.a, tiny) + fmin_(fmax_(b.qx, fmax_(b.qy, b.qz)), 0.0f);
+}
 // Leaves and the one operator with a parameter, as the generated code calls them: `r` points at the
 // record's parameters in LDS (wave-uniform address, constant offset: a broadcast read).
 template <bool FAST>
@@ -166,7 +218,8 @@ RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float d
 // Work list produced by the pre-pass (rm_tile_pre_v5 + rm_tile_sort_v5), one per frame.
 struct V5Work {
     const uint32_t* order;  // [n_frames][n_tiles] ids of the tiles that need marching, heaviest first
-    uint32_t* counters;     // [n_frames][2]: {number of such tiles, cursor of the persistent workgroups}
+    uint32_t* counters;     // [n_frames][4]: {number of such tiles, cursor of the persistent workgroups,
+                            //                 bits of f0 = map_scene(ro) (the shared first march step), unused}
 };
 
 // Persistent workgroups: the grid holds about as many workgroups as the chip has room for; each
@@ -201,10 +254,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
     const uint32_t tiles_x = (L.W + 7u) / 8u;
     const uint32_t* order = work.order + (size_t)blockIdx.z * n_tiles;
-    uint32_t* counters = work.counters + 2u * blockIdx.z;
+    uint32_t* counters = work.counters + 4u * blockIdx.z;
     const uint32_t n_active = counters[0];
 
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);  // wgsl:39-40
+    const float prune_scale = L.scene_scale + ((__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y)) + __builtin_fabsf(ro.z));  // "Pruning"
     const float eps = 0.0001f;                                    // wgsl:136
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
@@ -218,6 +272,35 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     Prog prog;
     if constexpr (PROG_IN_LDS) prog.base = lprog;
     else prog.base = L.prog;
+
+    // map_scene (wgsl:187-203) at one point per lane
+    auto eval_scene = [&](float x, float y, float z, float thr, bool is_live) -> float {
+        float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
+        uint32_t tiny = 0xFFFFFFFFu;
+        if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
+            v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
+            if (__ballot(tiny < kTinyBits) != 0ull)
+                v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
+        } else {
+            map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
+                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+        }
+        return v[0];
+    };
+
+    // The first march step of EVERY ray of the frame evaluates the same point: pos = ro + rd * 0 (wgsl:88-94).
+    // rm_tile_sort_v5 took it once per frame (f0); rays start from its outcome (wgsl:97-114 applied to f0):
+    //   START_HIT    f0 < min_dist: the hit is at ro, the ray goes straight to its normal taps
+    //   START_DONE   f0 > max_dist, or max_iter == 1: the loop ends without a hit
+    //   START_MARCH  dist = 0 + f0, one iteration used
+    // (only for finite rd: with a NaN / inf component rd * 0 is NaN and the ray starts the ordinary way)
+    enum : uint32_t { START_MARCH = 0u, START_HIT = 1u, START_DONE = 2u };
+    const float f0 = __uint_as_float(__builtin_amdgcn_readfirstlane(counters[2]));
+    uint32_t start = START_DONE;
+    if (L.max_iter != 0u)
+        start = f0 < L.min_dist ? START_HIT : (f0 > L.max_dist || L.max_iter <= 1u) ? START_DONE : START_MARCH;
+    const float inf_f = __uint_as_float(0x7F800000u);
 
     const unsigned long long t_start = L.stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
     uint32_t n_iter = 0u, n_live = 0u, n_prod = 0u, n_tiles_done = 0u;
@@ -242,6 +325,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     // lane state: evaluation point = b + d * sc
     float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
     uint32_t it = 0u, rid = 0u, mode = M_EMPTY;
+    float thr_base = __uint_as_float(0x7F800000u);  // SPEC: pruning threshold without its position term ("Pruning")
     uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u;  // wave-uniform cursors of the ready / shade buffers
     bool pool_open = true;                           // wave-uniform: the shared pool may still hold rays
 
@@ -283,7 +367,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                     const uint32_t r = base + lane, s = base >> 6;
                     float gx, gy, gz;
                     gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
-                    const bool culled = L.max_iter == 0u || ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+                    const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
+                    const bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
+                                        ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
                     if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                     const unsigned long long keep = __ballot(!culled);
                     if (!culled) {
@@ -304,9 +390,28 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         rid = rq_rid[e];
                         dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
                         bx = ro.x; by = ro.y; bz = ro.z;
-                        sc = 0.0f;  // dist (wgsl:88)
-                        it = 0u;
-                        mode = M_MARCH;
+                        const bool finite_d = __builtin_fabsf(dx) < inf_f && __builtin_fabsf(dy) < inf_f && __builtin_fabsf(dz) < inf_f;
+                        if (!finite_d) {  // rd * 0 is NaN: the first step is this ray's own
+                            sc = 0.0f;    // dist (wgsl:88)
+                            it = 0u;
+                            mode = M_MARCH;
+                            thr_base = inf_f;  // nothing is known yet
+                        } else if (start == START_HIT) {  // as the hit branch below, at pos = ro
+                            sc = eps;
+                            uint32_t sx, sy, sz;
+                            tap_signs(0u, sx, sy, sz);
+                            dx = __uint_as_float(0x3F800000u ^ sx);
+                            dy = __uint_as_float(0x3F800000u ^ sy);
+                            dz = __uint_as_float(0x3F800000u ^ sz);
+                            it = 0u;
+                            mode = M_TAP0;
+                            thr_base = __builtin_fabsf(f0) * 1.00001f + 1.75e-4f;
+                        } else {  // START_MARCH (START_DONE rays never get here)
+                            sc = 0.0f + f0;  // dist += scene_dist (wgsl:114)
+                            it = 1u;
+                            mode = M_MARCH;
+                            thr_base = __builtin_fabsf(f0) * 2.00002f;
+                        }
                     }
                 }
                 rq_pos += n_want < avail ? n_want : avail;
@@ -325,19 +430,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         n_live += (uint32_t)__popcll(live);
         uint32_t fin = 0u;  // 1: finished with a hit, 2: finished without
         {
-            float qx[1], qy[1], qz[1], v[1];
+            float qx[1], qy[1], qz[1];
             qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
-            uint32_t tiny = 0xFFFFFFFFu;
-            if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
-                v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), qx[0], qy[0], qz[0], tiny);
-                if (__ballot(tiny < kTinyBits) != 0ull)
-                    v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), qx[0], qy[0], qz[0], tiny);
-            } else {
-                map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-                if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
-                    map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-            }
-            const float sd = v[0];
+            float thr = inf_f;
+            if constexpr (SPEC) thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(qx[0]) + __builtin_fabsf(qy[0])) + __builtin_fabsf(qz[0])));
+            const float sd = eval_scene(qx[0], qy[0], qz[0], thr, mode < M_DONE_HIT);
             if (mode == M_MARCH) {
                 if (sd < L.min_dist) {  // wgsl:97: hit -> normal taps around pos = q
                     bx = qx[0]; by = qy[0]; bz = qz[0];
@@ -348,10 +445,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                     dy = __uint_as_float(0x3F800000u ^ sy);
                     dz = __uint_as_float(0x3F800000u ^ sz);
                     mode = M_TAP0;
+                    if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 1.00001f + 1.75e-4f;  // all four taps: |q - q_hit| = eps sqrt(3)
                 } else if (sd > L.max_dist) {  // wgsl:109-111
                     fin = 2u;
                 } else {
                     sc += sd;  // wgsl:114
+                    if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 2.00002f;  // the next point is |sd| |rd| away
                     it += 1u;
                     if (it >= L.max_iter) fin = 2u;  // loop bound, wgsl:90
                 }
@@ -594,10 +693,25 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
 // Work list of one frame (blockIdx.x = frame): ids of the tiles with cost > 0, by descending cost
 // when `balance` is set.  Also resets the persistent kernel's cursor.
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
-__global__ __launch_bounds__(1024) void rm_tile_sort_v5(const uint32_t* cost, uint32_t* order, uint32_t* counters,
+__global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32_t* cost, uint32_t* order, uint32_t* counters,
                                                         uint32_t n_tiles, uint32_t balance) {
     __shared__ uint32_t hist[65], base[65];
+    __shared__ float f0_spill[32 * 64];
     const uint32_t tid = threadIdx.x;
+    // f0 = map_scene(ro): the first march step every ray of this frame shares (see rm_render_v5_body).  The
+    // interpreter with the correctly rounded library sqrt gives the same bits as every kernel's evaluation.
+    if (tid >= 960u) {  // the last wave; it has the least to do in the loops below
+        rm_uniforms u = L.u;
+        if (L.frames) u = L.frames[blockIdx.x];
+        const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
+        ProgSmem prog;
+        prog.base = L.prog;
+        const float qx[1] = {ro.x}, qy[1] = {ro.y}, qz[1] = {ro.z};
+        float v[1];
+        uint32_t tiny = 0xFFFFFFFFu;
+        map_scene_multi<1, false, ProgSmem, true>(prog, L.n_rec, f0_spill + (tid & 63u), L.max_dist, qx, qy, qz, v, tiny);
+        if (tid == 960u) counters[4u * blockIdx.x + 2u] = __float_as_uint(v[0]);
+    }
     const uint32_t* c = cost + (size_t)blockIdx.x * n_tiles;
     uint32_t* o = order + (size_t)blockIdx.x * n_tiles;
     if (tid < 65u) hist[tid] = 0u;
@@ -616,8 +730,8 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(const uint32_t* cost, ui
     if (tid == 0u) {
         uint32_t acc = 0u;
         for (uint32_t b = 0; b < 65u; b++) { base[b] = acc; acc += hist[b]; }
-        counters[2u * blockIdx.x] = acc;      // tiles on the work list
-        counters[2u * blockIdx.x + 1u] = 0u;  // cursor
+        counters[4u * blockIdx.x] = acc;      // tiles on the work list
+        counters[4u * blockIdx.x + 1u] = 0u;  // cursor
     }
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u) {

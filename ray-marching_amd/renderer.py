@@ -186,12 +186,13 @@ def validate_program(cmd_count, words):
     return rc, depth.value
 
 
-def jit_source(cmd_count, words, waves_per_tile=4):
+def jit_source(cmd_count, words, waves_per_tile=4, prune=False):
     """rm_jit_source: the HIP source the structure specialiser generates for a command stream (no GPU needed)."""
     w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
     ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
     L = _ffi.hip_lib()
     need = C.c_size_t(0)
+    waves_per_tile = int(waves_per_tile) | (_ffi.RM_JIT_PRUNE if prune else 0)
     rc = L.rm_jit_source(int(cmd_count), ptr, int(w.size), int(waves_per_tile), None, 0, C.byref(need))
     if rc != _ffi.RM_OK:
         raise _ffi.RmError(rc, L.rm_status_string(rc).decode())
@@ -200,13 +201,14 @@ def jit_source(cmd_count, words, waves_per_tile=4):
     return buf.value.decode()
 
 
-def jit_compile(cmd_count, words, waves_per_tile=4):
+def jit_compile(cmd_count, words, waves_per_tile=4, prune=False):
     """rm_jit_compile: compile the specialised kernel for gfx950 with hipRTC, without loading it (no GPU needed).
     Returns (status, compile_ms, code_bytes, log)."""
     w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
     ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
     ms, nbytes = C.c_double(0.0), C.c_size_t(0)
     log = C.create_string_buffer(1 << 16)
+    waves_per_tile = int(waves_per_tile) | (_ffi.RM_JIT_PRUNE if prune else 0)
     rc = _ffi.hip_lib().rm_jit_compile(int(cmd_count), ptr, int(w.size), int(waves_per_tile), C.byref(ms),
                                        C.byref(nbytes), log, len(log))
     return rc, ms.value, nbytes.value, log.value.decode(errors="replace")

@@ -27,9 +27,10 @@ def case(oracle, scene, W, H):
     return cc, w, u
 
 
-def load(res, cc, w, u, mode):
+def load(res, cc, w, u, mode, prune=0):
     res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
     res.set_option(_ffi.RM_OPT_SPECIALIZE, mode)
+    res.set_option(_ffi.RM_OPT_PRUNE, prune)
     res.set_limits(LIM)
     res.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
     res.set_program(cc, w)
@@ -52,8 +53,12 @@ def test_specialised_equals_interpreter_equals_oracle(res, oracle, name):
     assert res.info(_ffi.RM_INFO_JIT_STATE) == 2, res.jit_log()
     assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
     assert res.info(_ffi.RM_INFO_JIT_COMPILE_MS) > 0
+    load(res, cc, w, u, 2, prune=1)
+    pruned = res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1, res.jit_log()
     ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
     assert spec.tobytes() == ref.tobytes()
+    assert pruned.tobytes() == ref.tobytes()
     assert interp.tobytes() == ref.tobytes()
 
 
@@ -179,5 +184,8 @@ def test_full_size_metric_config_specialised_vs_interpreter(res, oracle):
     b = res.draw(W, H)
     assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
     assert a.tobytes() == b.tobytes()
+    load(res, cc, w, u, 2, prune=1)
+    res.set_limits(lim)
+    assert res.draw(W, H).tobytes() == a.tobytes()
     for r0, rows in [(200, 3), (540, 4), (901, 3)]:
         assert b[r0:r0 + rows].tobytes() == oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=8).tobytes()

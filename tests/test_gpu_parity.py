@@ -22,9 +22,10 @@ KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_
 # pseudo variant: the default kernel with its structure-specialised (hipRTC) march kernel, compiled synchronously;
 # every explicitly named variant above runs with specialisation off, i.e. the interpreter kernels
 KERNEL_SPEC = 1000
-KERNELS.append(KERNEL_SPEC)
+KERNEL_SPEC_PRUNE = 1001     # ... plus far-primitive pruning (RM_OPT_PRUNE = 1; opt-in)
+KERNELS += [KERNEL_SPEC, KERNEL_SPEC_PRUNE]
 KERNEL_IDS = ["pixel", "raypool", "raypool_lds", "multi1", "multi1_lds", "multi2", "multi2_lds", "multi4",
-              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds", "v5_spec"]
+              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds", "v5_spec", "v5_spec_prune"]
 IDX = G.index()
 
 
@@ -45,9 +46,10 @@ def assert_same(img, ref):
 
 
 def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kernel=_ffi.RM_KERNEL_DEFAULT):
-    spec = kernel in (KERNEL_SPEC, _ffi.RM_KERNEL_DEFAULT)
+    spec = kernel in (KERNEL_SPEC, KERNEL_SPEC_PRUNE, _ffi.RM_KERNEL_DEFAULT)
     res.set_option(_ffi.RM_OPT_SPECIALIZE, 2 if spec else 0)
-    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5_LDS if kernel == KERNEL_SPEC else kernel)
+    res.set_option(_ffi.RM_OPT_PRUNE, 1 if kernel == KERNEL_SPEC_PRUNE else 0)
+    res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5_LDS if kernel in (KERNEL_SPEC, KERNEL_SPEC_PRUNE) else kernel)
     res.set_limits(limits)
     res.set_uniforms(u)
     res.set_program(cc, words)
@@ -57,7 +59,7 @@ def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kern
 @pytest.mark.parametrize("name", sorted(n for n in IDX if "file" in IDX[n]))
 def test_golden_fixtures(res, name, kernel):
     e = IDX[name]
-    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC):
+    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE):
         pytest.skip("only the v5 kernels render extension node types")
     u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
     setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
@@ -172,8 +174,8 @@ CULL_CAMERAS = {
 @pytest.mark.parametrize("cam", sorted(CULL_CAMERAS))
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2,
                                     _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5,
-                                    _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
-                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds", "v5_spec"])
+                                    _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE],
+                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds", "v5_spec", "v5_spec_prune"])
 def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
     """The bounding-cone shortcut must never change a pixel: culling on == culling off == oracle,
     for cameras outside, inside, far from and grazing the scene, and for several min_dist."""
@@ -202,8 +204,9 @@ def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
             assert_same(bal, ref)
 
 
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
-                         ids=["multi1_lds", "queue_lds", "v5_lds", "v5_spec"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC,
+                                    KERNEL_SPEC_PRUNE],
+                         ids=["multi1_lds", "queue_lds", "v5_lds", "v5_spec", "v5_spec_prune"])
 def test_culling_with_arbitrary_uniform_matrices(res, oracle, kernel):
     """The uniform block is three opaque blobs to the pipeline: the miss tests must hold for ANY matrices, not
     only the reference camera's.  wgsl:62 normalises a vec4, so whenever pt_world.w != ro.w the ray direction
@@ -309,8 +312,8 @@ def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     assert res.draw_strips(W, H, 32, 7, 8).shape[0] == 0   # more ranks than strips: empty share
 
 
-EXT_KERNELS = [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC]  # older kernels: reference nodes only
-EXT_IDS = ["default", "v5", "v5_lds", "v5_spec"]
+EXT_KERNELS = [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE]  # older kernels: reference nodes only
+EXT_IDS = ["default", "v5", "v5_lds", "v5_spec", "v5_spec_prune"]
 
 
 @pytest.mark.parametrize("kernel", EXT_KERNELS, ids=EXT_IDS)

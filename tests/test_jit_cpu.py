@@ -21,48 +21,80 @@ def map_scene_body(src):
 
 
 def test_generated_code_follows_the_postfix_program(oracle):
-    """One call per leaf in program order, one combine per operator, operands resolved like the value stack
-    of ray_marching.wgsl:187-203 would."""
+    """One leaf evaluation per primitive in program order, one combine per operator, operands resolved like the
+    value stack of ray_marching.wgsl:187-203 would; sphere / box leaves sit behind the wave-uniform far test."""
     cc, w = serialize(oracle, scenes.g8())     # ((S u B) - S) u B
-    body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w))]
-    assert body == [
+    plain = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w))]
+    assert plain == [
         "const float v0 = spec_sphere<FAST>(lp + 1, qx, qy, qz, tiny);",
-        "const float v1 = spec_box<FAST>(lp + 9, qx, qy, qz, tiny);",
-        "const float v2 = vmin(v0, v1);",
-        "const float v3 = spec_sphere<FAST>(lp + 17, qx, qy, qz, tiny);",
-        "const float v4 = vmax_negb(v2, v3);",
-        "const float v5 = spec_box<FAST>(lp + 25, qx, qy, qz, tiny);",
-        "const float v6 = vmin(v4, v5);",
-        "return v6;",
+        "const float v1 = vmin(v0, spec_box<FAST>(lp + 9, qx, qy, qz, tiny));",
+        "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 17, qx, qy, qz, tiny));",
+        "const float v3 = vmin(v2, spec_box<FAST>(lp + 25, qx, qy, qz, tiny));",
+        "return v3;",
+    ]
+    body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True))]
+    assert body[:3] == ["const float thrk = thr * 1.000005f;", "const float thr2k = (thr * thr) * 1.00001f;",
+                        "const float inf = __uint_as_float(0x7F800000u);"]
+    assert body[3:] == [
+        "float v0 = inf;",
+        "{ const float a = spec_sphere_a(lp + 1, qx, qy, qz);",
+        "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); }",
+        "float v1 = v0;",
+        "{ const SpecBox b = spec_box_a(lp + 9, qx, qy, qz);",
+        "if (spec_any_near(live, b.a > thr2k)) v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); }",
+        "float v2 = v1;",
+        "{ const float a = spec_sphere_a(lp + 17, qx, qy, qz);",
+        "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); }",
+        "float v3 = v2;",
+        "{ const SpecBox b = spec_box_a(lp + 25, qx, qy, qz);",
+        "if (spec_any_near(live, b.a > thr2k)) v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); }",
+        "return v3;",
     ]
 
 
-def evaluate_generated(body, nodes_params, pos):
-    """Interpret the generated straight-line code with plain float64 SDFs: a structural check only."""
+def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
+    """Interpret the generated straight-line code with plain float64 SDFs: a structural check only.
+    prune_all_far(value) -> bool decides whether a leaf counts as far for the (single) lane."""
     import math
-    env = {}
+
+    def sphere(rec):
+        p = nodes_params[rec]
+        return math.sqrt(sum((pos[i] - p[i]) ** 2 for i in range(3))) - p[3]
+
+    def box(rec):
+        p = nodes_params[rec]
+        q = [abs(pos[i] - p[i]) - p[3 + i] for i in range(3)]
+        return math.sqrt(sum(max(x, 0.0) ** 2 for x in q)) + min(max(q), 0.0)
+
+    ops = {"vmin": min, "vmax_negb": lambda a, b: max(a, -b), "fmax_": max}
+    env = {"inf": math.inf}
+    pending = None
     for line in body:
-        line = line.strip().rstrip(";")
+        line = line.strip()
+        if line.startswith("const float thr") or line.startswith("const float inf"):
+            continue
         if line.startswith("return"):
-            return env[line.split()[1]]
-        name, expr = line[len("const float "):].split(" = ")
-        m = re.match(r"(\w+)(?:<FAST>)?\((.*)\)", expr)
-        fn, args = m.group(1), [a.strip() for a in m.group(2).split(",")]
-        if fn in ("spec_sphere", "spec_box"):
-            rec = (int(args[0].split("+")[1]) - 1) // 8
-            p = nodes_params[rec]
-            d = [pos[i] - p[i] for i in range(3)]
-            if fn == "spec_sphere":
-                env[name] = math.sqrt(sum(x * x for x in d)) - p[3]
-            else:
-                q = [abs(d[i]) - p[3 + i] for i in range(3)]
-                env[name] = math.sqrt(sum(max(x, 0.0) ** 2 for x in q)) + min(max(q), 0.0)
-        elif fn == "vmin":
-            env[name] = min(env[args[0]], env[args[1]])
-        elif fn == "vmax_negb":
-            env[name] = max(env[args[0]], -env[args[1]])
-        else:
-            raise AssertionError(fn)
+            return env[line.rstrip(";").split()[1]]
+        m = re.match(r"float (v\d+) = (\w+);", line)
+        if m:
+            env[m.group(1)] = env[m.group(2)]
+            continue
+        m = re.match(r"\{ const (?:float a = spec_sphere_a|SpecBox b = spec_box_a)\(lp \+ (\d+),", line)
+        if m:
+            rec = (int(m.group(1)) - 1) // 8
+            pending = sphere(rec) if "sphere" in line else box(rec)
+            continue
+        m = re.match(r"if \(spec_any_near\(.*?\)\) (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \}", line)
+        if m:
+            tgt, op, acc = m.groups()
+            if not (prune_all_far and prune_all_far(pending)):
+                env[tgt] = pending if op is None else ops[op](env[acc], pending)
+            continue
+        m = re.match(r"const float (v\d+) = (\w+)\((v\d+), (v\d+)\);", line)
+        if m:
+            env[m.group(1)] = ops[m.group(2)](env[m.group(3)], env[m.group(4)])
+            continue
+        raise AssertionError("unparsed line: " + line)
     raise AssertionError("no return")
 
 
@@ -70,7 +102,7 @@ def evaluate_generated(body, nodes_params, pos):
 def test_generated_code_evaluates_like_the_oracle(oracle, name):
     scene = scenes.right_deep(6) if name == "right_deep6" else scenes.SCENES[name]()
     cc, w = serialize(oracle, scene)
-    body = map_scene_body(renderer.jit_source(cc, w))
+    body = map_scene_body(renderer.jit_source(cc, w, prune=True))
     # parameters per decoded record: leaves in program order; fused operators share their leaf's record,
     # operators on sub-trees have a record of their own (rm_decode.h)
     params, ptr, i = [], 0, 0
@@ -92,9 +124,14 @@ def test_generated_code_evaluates_like_the_oracle(oracle, name):
         i += 1
     rng = np.random.default_rng(5)
     for pos in rng.uniform(-3, 3, size=(50, 3)):
-        got = evaluate_generated(body, params, [float(x) for x in pos])
+        p = [float(x) for x in pos]
+        got = evaluate_generated(body, params, p)
         want = oracle.map_scene(cc, w, [float(np.float32(x)) for x in pos])
         assert abs(got - want) < 1e-4 * max(1.0, abs(want))
+        # the pruning rule: with |F| <= thr known, dropping every leaf whose value exceeds thr changes nothing
+        for slack in (1.0, 1.5, 4.0):
+            thr = abs(got) * slack + 1e-9
+            assert evaluate_generated(body, params, p, prune_all_far=lambda v: v > thr) == got
 
 
 def test_same_structure_same_source_different_structure_different_source(oracle):
@@ -121,11 +158,12 @@ def test_source_rejects_what_cannot_be_specialised(oracle):
         renderer.jit_source(cc, w, 3)
 
 
+@pytest.mark.parametrize("prune", [False, True], ids=["plain", "prune"])
 @pytest.mark.parametrize("name", ["g8", "g64", "ext_mix"])
-def test_generated_kernel_compiles_for_gfx950(oracle, name):
+def test_generated_kernel_compiles_for_gfx950(oracle, name, prune):
     scene = (scenes.SCENES.get(name) or scenes.EXT_SCENES[name])()
     cc, w = serialize(oracle, scene)
-    rc, ms, nbytes, log = renderer.jit_compile(cc, w)
+    rc, ms, nbytes, log = renderer.jit_compile(cc, w, prune=prune)
     if rc != _ffi.RM_OK and "could not be loaded" in log:
         pytest.skip("libhiprtc is not installed: " + log)
     assert rc == _ffi.RM_OK, log
