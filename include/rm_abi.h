@@ -202,8 +202,10 @@ int rm_get_info(rm_ctx* ctx, int key, double* out);
 int rm_measure_write_bandwidth(rm_ctx* ctx, uint64_t bytes, int iters, double* out_gbps);
 
 /* Self-tests of the arithmetic building blocks (used by tests/test_gpu_arithmetic.py).
- * rm_selftest_sqrt: runs the kernels' short correctly-rounded sqrt against the generic one on ALL 2^32 binary32
- * bit patterns (restricted to its stated domain: 0, [2^-96, +inf], NaN); *out_mismatches must come back 0.
+ * rm_selftest_sqrt: runs the kernels' short correctly-rounded sqrt (v_rsq_f32 + one FMA-form Newton step, with its range
+ * guard) against the generic one on EVERY non-negative binary32 bit pattern: wherever the guard lets the short form
+ * through, the result must be the correctly rounded root, and the guard must not reject anything in [2^-96, FLT_MAX];
+ * *out_mismatches must come back 0.
  * rm_selftest_ops: out[k*n + i], k = 0..7: min(a,b), max(a,b), v_min_f32(a,b), v_max_f32(a,-b), short sqrt(a),
  * generic sqrt(a), a / b, (float) i32(round(a)) -- compared on the host with the oracle's definitions. */
 int rm_selftest_sqrt(rm_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_bad_bits);

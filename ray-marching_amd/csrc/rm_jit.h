@@ -117,7 +117,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     char line[512];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, uint32_t& tiny) {\n";
+    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny) {\n";
     if (prune) {
         s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test
@@ -202,6 +202,10 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     s += "#include \"rm_kernel_v5.h\"\n";
     s += body;
     char line[512];
+    if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) {  // experiment knob: cap the VGPR budget
+        std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", std::atoi(w), std::atoi(w));
+        s += line;
+    }
     std::snprintf(line, sizeof line,
                   "extern \"C\" __global__ __launch_bounds__(%d) void %s(RmLaunch L, rmk::V5Work work, uint32_t n_tiles, "
                   "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true>(L, work, n_tiles, refill_min);\n}\n",

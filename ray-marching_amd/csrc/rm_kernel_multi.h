@@ -34,56 +34,68 @@ RM_DEV float vmax_negb(float a, float b) {  // max(a, -b)
     return r;
 }
 
-// Correctly rounded sqrt for x == 0, x >= 2^-96, +inf and NaN in 9 VALU + v_sqrt_f32: the
-// core of LLVM's own f32 sqrt expansion (1-ulp v_sqrt_f32, then step to the neighbour whose
-// exact residual x - s*s' says it is closer) WITHOUT the 2^32 pre-scaling and the class
-// fix-up the generic lowering needs for denormal-range inputs.  Inputs in (0, 2^-96) are NOT
-// handled here: the caller tracks them (see `tiny`) and re-evaluates with __builtin_sqrtf.
-RM_DEV float sqrt_rn_fast(float x) {
-    float s = __builtin_amdgcn_sqrtf(x);
-    const float sd = __uint_as_float(__float_as_uint(s) - 1u);
-    const float su = __uint_as_float(__float_as_uint(s) + 1u);
-    const float vp = __builtin_fmaf(-sd, s, x);
-    const float vs = __builtin_fmaf(-su, s, x);
-    s = vp <= 0.0f ? sd : s;
-    s = vs > 0.0f ? su : s;
-    return s;
+// Correctly rounded sqrt in v_rsq_f32 + 4 VALU:  y = rsq(x); g = x y; s = g + (x - g g) (y / 2), the residual and
+// the final sum each one FMA.  v_rsq_f32 is a 1-ulp approximation, g is within ~1.5 ulp of sqrt(x), the residual
+// x - g g is exact, and the rounding of the final FMA lands on the correctly rounded root for EVERY binary32 x in
+// [2^-102, FLT_MAX]: established by exhaustion on MI355X (tools/probe_sqrt_range.hip; rm_selftest_sqrt repeats it
+// on whatever GPU the library runs on), not by a proof.  It replaces v_sqrt_f32 + the 8-instruction neighbour test
+// of LLVM's expansion (which this file used before: 9 VALU + v_sqrt_f32).  Outside that range -- 0, inf, NaN,
+// denormals -- the sequence returns NaN or garbage: the caller tracks the range of all arguments of one map_scene
+// evaluation in a SqrtGuard and re-evaluates with __builtin_sqrtf when any lane saw an argument outside
+// [2^-96, FLT_MAX].  Zero is a legitimate and frequent argument for boxes (inside the slab), so ZERO_OK clamps the
+// v_rsq input (g = 0 * y = 0, residual 0, result +0) and keeps zero out of the guard; spheres hit zero only at
+// their exact centre and take the slow path there.
+struct SqrtGuard {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;  // min / max over the (biased) bit patterns of all sqrt arguments
+    RM_DEV bool bad() const { return lo < kLoBits || hi > 0x7F7FFFFFu; }
+    static constexpr uint32_t kLoBits = 0x0F800000u - 1u;  // bits(2^-96) - 1
+};
+RM_DEV float vmax(float a, float b) {  // direct v_max_f32, see vmin
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
-// (bits(x) - 1) as unsigned is < kTinyBits exactly for 0 < x < 2^-96 (x >= +0 here).
-constexpr uint32_t kTinyBits = 0x0F800000u - 1u;  // bits(2^-96) - 1
+template <bool ZERO_OK>
+RM_DEV float sqrt_rn_fast(float x) {
+    const float y = __builtin_amdgcn_rsqf(ZERO_OK ? vmax(x, __uint_as_float(0x0F800000u)) : x);
+    const float g = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
 
-template <bool FAST>
-RM_DEV float sqrt_sel(float x, uint32_t& tiny) {
+template <bool FAST, bool ZERO_OK = false>
+RM_DEV float sqrt_sel(float x, SqrtGuard& guard) {
     if constexpr (FAST) {
-        tiny = min(tiny, __float_as_uint(x) - 1u);
-        return sqrt_rn_fast(x);
+        // x >= +0 or NaN here (sums of squares).  ZERO_OK: (bits - 1) wraps 0 to the top, so only 0 < x < 2^-96 is low.
+        guard.lo = min(guard.lo, ZERO_OK ? __float_as_uint(x) - 1u : __float_as_uint(x));
+        guard.hi = max(guard.hi, __float_as_uint(x));
+        return sqrt_rn_fast<ZERO_OK>(x);
     } else {
         return __builtin_sqrtf(x);
     }
 }
 
 template <bool FAST>
-RM_DEV float sdf_sphere_t(float px, float py, float pz, const float (&p)[7], uint32_t& tiny) {
+RM_DEV float sdf_sphere_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
     const float dx = px - p[0], dy = py - p[1], dz = pz - p[2];
     return sqrt_sel<FAST>((dx * dx + dy * dy) + dz * dz, tiny) - p[3];
 }
 template <bool FAST>
-RM_DEV float sdf_box_t(float px, float py, float pz, const float (&p)[7], uint32_t& tiny) {
+RM_DEV float sdf_box_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
     const float qx = __builtin_fabsf(px - p[0]) - p[3];
     const float qy = __builtin_fabsf(py - p[1]) - p[4];
     const float qz = __builtin_fabsf(pz - p[2]) - p[5];
     const float mx = fmax_(qx, 0.0f), my = fmax_(qy, 0.0f), mz = fmax_(qz, 0.0f);
-    return sqrt_sel<FAST>((mx * mx + my * my) + mz * mz, tiny) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f);
+    return sqrt_sel<FAST, true>((mx * mx + my * my) + mz * mz, tiny) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f);
 }
 
 template <bool FAST>
-RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], uint32_t& tiny) {
+RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
     // extension: capped cylinder along y.  p = cx cy cz radius half_height
     const float dx = px - p[0], dz = pz - p[2];
-    const float qx = sqrt_sel<FAST>(dx * dx + dz * dz, tiny) - p[3];
+    const float qx = sqrt_sel<FAST, true>(dx * dx + dz * dz, tiny) - p[3];
     const float qy = __builtin_fabsf(py - p[1]) - p[4];
     const float mx = fmax_(qx, 0.0f), my = fmax_(qy, 0.0f);
-    return fmin_(fmax_(qx, qy), 0.0f) + sqrt_sel<FAST>(mx * mx + my * my, tiny);
+    return fmin_(fmax_(qx, qy), 0.0f) + sqrt_sel<FAST, true>(mx * mx + my * my, tiny);
 }
 
 // One decoded command applied to the R positions of a lane.
@@ -91,7 +103,7 @@ RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], u
 // adds the extension node types.  Which one runs is decided per program on the host.
 template <int R, bool FAST, bool EXT = false>
 RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R], const float (&qy)[R],
-                         const float (&qz)[R], float (&acc)[R], float* spill, uint32_t& sp, uint32_t& tiny) {
+                         const float (&qz)[R], float (&acc)[R], float* spill, uint32_t& sp, SqrtGuard& tiny) {
     // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
@@ -158,7 +170,7 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R],
 // of the previous command.
 template <int R, bool FAST, class Prog, bool EXT = false>
 RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx)[R],
-                            const float (&qy)[R], const float (&qz)[R], float (&out)[R], uint32_t& tiny) {
+                            const float (&qy)[R], const float (&qz)[R], float (&out)[R], SqrtGuard& tiny) {
     if (n_rec == 0u) {  // wgsl:189-191
 #pragma unroll
         for (int k = 0; k < R; k++) out[k] = max_dist;
@@ -402,9 +414,9 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_raypool_multi(RmLaunch L, 
         }
         n_iter++;
         n_live += (uint32_t)__popcll(live_any);
-        uint32_t tiny = 0xFFFFFFFFu;
+        SqrtGuard tiny;
         map_scene_multi<R, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-        if (__ballot(tiny < kTinyBits) != 0ull)  // some sqrt argument in (0, 2^-96): redo with the generic sqrt
+        if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
             map_scene_multi<R, false>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
 
 #pragma unroll
@@ -544,8 +556,9 @@ __global__ __launch_bounds__(1024) void rm_tile_sort(const uint32_t* cost, uint3
 // ---------------------------------------------------------------------------------------------
 // Self-tests of the arithmetic building blocks (diagnostics, rm_selftest_* in the ABI).
 // ---------------------------------------------------------------------------------------------
-// Exhaustive: sqrt_rn_fast(x) == correctly rounded sqrt for EVERY binary32 x in its stated domain
-// (x == 0, x >= 2^-96, +inf, NaN), i.e. for all bit patterns in [first, first + count).
+// Exhaustive: for EVERY binary32 bit pattern x >= +0 (what a sum of squares can be) and both forms of the guarded
+// fast sqrt, either the guard sends the evaluation to the generic path or the result is the correctly rounded root.
+// Also counts the in-range inputs the guard rejects: must be none besides 0 for the ZERO_OK = false form.
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
 __global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* mismatches,
                                                                uint32_t* first_bad) {
@@ -553,12 +566,22 @@ __global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, u
     unsigned long long bad = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) {
         const uint32_t bits = first + (uint32_t)i;
+        if (bits > 0x7FFFFFFFu && bits != 0xFFC00000u) continue;  // negative: never an argument (one NaN with the sign set stays in)
         const float x = __uint_as_float(bits);
-        const bool in_domain = (bits == 0u) || (bits >= 0x0F800000u && bits <= 0x7F800000u) || (x != x);
-        if (!in_domain) continue;  // negative numbers and (0, 2^-96): handled by the generic path
-        const float a = sqrt_rn_fast(x), b = __builtin_sqrtf(x);
-        const bool same = (a != a && b != b) || __float_as_uint(a) == __float_as_uint(b);
-        if (!same) {
+        const float want = __builtin_sqrtf(x);
+        const bool in_range = bits >= 0x0F800000u && bits <= 0x7F7FFFFFu;
+        bool ok = true;
+        {
+            SqrtGuard g;
+            const float a = sqrt_sel<true, false>(x, g);
+            ok = ok && (g.bad() ? !in_range : __float_as_uint(a) == __float_as_uint(want));
+        }
+        {
+            SqrtGuard g;
+            const float a = sqrt_sel<true, true>(x, g);
+            ok = ok && (g.bad() ? !(in_range || bits == 0u) : __float_as_uint(a) == __float_as_uint(want));
+        }
+        if (!ok) {
             bad++;
             atomicMin(first_bad, bits);
         }
@@ -579,9 +602,9 @@ __global__ __launch_bounds__(256) void rm_selftest_ops_kernel(const float* a, co
     out[1u * n + i] = fmax_(x, y);
     out[2u * n + i] = vmin(x, y);
     out[3u * n + i] = vmax_negb(x, y);
-    const uint32_t bits = __float_as_uint(x);
-    const bool in_domain = (bits == 0u) || (bits >= 0x0F800000u && bits <= 0x7F800000u) || (x != x);
-    out[4u * n + i] = in_domain ? sqrt_rn_fast(x) : __builtin_sqrtf(x);
+    SqrtGuard guard;
+    const float fast = sqrt_sel<true, true>(x, guard);  // what a kernel does: fast form unless the guard objects
+    out[4u * n + i] = guard.bad() ? __builtin_sqrtf(x) : fast;
     out[5u * n + i] = __builtin_sqrtf(x);
     out[6u * n + i] = x / y;
     out[7u * n + i] = (float)__float2int_rz(__builtin_rintf(x));

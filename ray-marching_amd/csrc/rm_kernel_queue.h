@@ -134,9 +134,9 @@ __global__ __launch_bounds__(64) void rm_render_queue(RmLaunch L) {
         if (mode < M_DONE_HIT) {
             float qx[1], qy[1], qz[1], v[1];
             qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
-            uint32_t tiny = 0xFFFFFFFFu;
+            SqrtGuard tiny;
             map_scene_multi<1, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-            if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
+            if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
                 map_scene_multi<1, false>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
             const float sd = v[0];
             if (mode == M_MARCH) {

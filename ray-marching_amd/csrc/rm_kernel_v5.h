@@ -34,7 +34,7 @@ namespace rmk {
 //   lp: the decoded program in LDS (RmRecord[n], 8 dwords each: parameters are read at fixed offsets)
 //   thr, live: far-primitive pruning, see below
 template <bool FAST>
-RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, uint32_t& tiny);
+RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny);
 
 // ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
 // A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
@@ -71,7 +71,7 @@ RM_DEV bool spec_sphere_far(const float* r, float a, float thrk) {
     return a > t * t;
 }
 template <bool FAST>
-RM_DEV float spec_sphere_v(const float* r, float a, uint32_t& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
+RM_DEV float spec_sphere_v(const float* r, float a, SqrtGuard& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(const float* r, float px, float py, float pz) {
     SpecBox b;
@@ -83,23 +83,23 @@ RM_DEV SpecBox spec_box_a(const float* r, float px, float py, float pz) {
     return b;
 }
 template <bool FAST>
-RM_DEV float spec_box_v(const SpecBox& b, uint32_t& tiny) {
-    return sqrt_sel<FAST>(b.a, tiny) + fmin_(fmax_(b.qx, fmax_(b.qy, b.qz)), 0.0f);
+RM_DEV float spec_box_v(const SpecBox& b, SqrtGuard& tiny) {
+    return sqrt_sel<FAST, true>(b.a, tiny) + fmin_(fmax_(b.qx, fmax_(b.qy, b.qz)), 0.0f);
 }
 // Leaves and the one operator with a parameter, as the generated code calls them: `r` points at the
 // record's parameters in LDS (wave-uniform address, constant offset: a broadcast read).
 template <bool FAST>
-RM_DEV float spec_sphere(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+RM_DEV float spec_sphere(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], 0.0f, 0.0f, 0.0f};
     return sdf_sphere_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
-RM_DEV float spec_box(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+RM_DEV float spec_box(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], r[4], r[5], 0.0f};
     return sdf_box_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
-RM_DEV float spec_cylinder(const float* r, float qx, float qy, float qz, uint32_t& tiny) {
+RM_DEV float spec_cylinder(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], r[4], 0.0f, 0.0f};
     return sdf_cylinder_t<FAST>(qx, qy, qz, p, tiny);
 }
@@ -276,14 +276,14 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     // map_scene (wgsl:187-203) at one point per lane
     auto eval_scene = [&](float x, float y, float z, float thr, bool is_live) -> float {
         float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
-        uint32_t tiny = 0xFFFFFFFFu;
+        SqrtGuard tiny;
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
             v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
-            if (__ballot(tiny < kTinyBits) != 0ull)
+            if (__ballot(tiny.bad()) != 0ull)
                 v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
-            if (__ballot(tiny < kTinyBits) != 0ull)  // a sqrt argument in (0, 2^-96): redo with the generic sqrt
+            if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
                 map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
         }
         return v[0];
@@ -708,7 +708,7 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32
         prog.base = L.prog;
         const float qx[1] = {ro.x}, qy[1] = {ro.y}, qz[1] = {ro.z};
         float v[1];
-        uint32_t tiny = 0xFFFFFFFFu;
+        SqrtGuard tiny;
         map_scene_multi<1, false, ProgSmem, true>(prog, L.n_rec, f0_spill + (tid & 63u), L.max_dist, qx, qy, qz, v, tiny);
         if (tid == 960u) counters[4u * blockIdx.x + 2u] = __float_as_uint(v[0]);
     }
