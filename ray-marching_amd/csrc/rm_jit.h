@@ -113,11 +113,12 @@ inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty
 // rm_kernel_v5.h ("Pruning").  Returns false if the records do not form a valid program (cannot
 // happen for the output of rm_decode_program).
 inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
+    const bool count = prune && std::getenv("RM_JIT_PRUNE_STATS") != nullptr;  // diagnostics: count evaluated leaves
     std::string s;
     char line[512];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny) {\n";
+    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
     if (prune) {
         s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test
@@ -164,8 +165,8 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
                 std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
             }
             s += line;
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "v%d = %s; }\n", w, leaf);
-            else std::snprintf(line, sizeof line, "v%d = %s(v%d, %s); }\n", w, op, a, leaf);
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "{ v%d = %s; %s} }\n", w, leaf, count ? "n_eval += 1u; " : "");
+            else std::snprintf(line, sizeof line, "{ v%d = %s(v%d, %s); %s} }\n", w, op, a, leaf, count ? "n_eval += 1u; " : "");
             s += line;
         } else {
             const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"

@@ -34,7 +34,7 @@ namespace rmk {
 //   lp: the decoded program in LDS (RmRecord[n], 8 dwords each: parameters are read at fixed offsets)
 //   thr, live: far-primitive pruning, see below
 template <bool FAST>
-RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny);
+RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval);
 
 // ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
 // A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
@@ -273,14 +273,17 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     if constexpr (PROG_IN_LDS) prog.base = lprog;
     else prog.base = L.prog;
 
+    uint32_t n_eval = 0u;  // diagnostics (pruned kernels compiled with statistics): leaves actually evaluated, per wave
     // map_scene (wgsl:187-203) at one point per lane
     auto eval_scene = [&](float x, float y, float z, float thr, bool is_live) -> float {
         float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
         SqrtGuard tiny;
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
-            v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
-            if (__ballot(tiny.bad()) != 0ull)
-                v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny);
+            v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny, n_eval);
+            if (__ballot(tiny.bad()) != 0ull) {
+                uint32_t again = 0u;
+                v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny, again);
+            }
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
             if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
@@ -529,7 +532,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         st[0] = t_start;
         st[1] = __builtin_amdgcn_s_memrealtime();
         st[2] = ((unsigned long long)n_tiles_done << 32) | n_iter;
-        st[3] = ((unsigned long long)n_prod << 32) | n_live;
+        st[3] = ((unsigned long long)(n_eval != 0u ? n_eval : n_prod) << 32) | n_live;
     }
 }
 

@@ -38,16 +38,16 @@ def test_generated_code_follows_the_postfix_program(oracle):
     assert body[3:] == [
         "float v0 = inf;",
         "{ const float a = spec_sphere_a(lp + 1, qx, qy, qz);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); }",
+        "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); } }",
         "float v1 = v0;",
         "{ const SpecBox b = spec_box_a(lp + 9, qx, qy, qz);",
-        "if (spec_any_near(live, b.a > thr2k)) v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); }",
+        "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
         "{ const float a = spec_sphere_a(lp + 17, qx, qy, qz);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); }",
+        "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); } }",
         "float v3 = v2;",
         "{ const SpecBox b = spec_box_a(lp + 25, qx, qy, qz);",
-        "if (spec_any_near(live, b.a > thr2k)) v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); }",
+        "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
         "return v3;",
     ]
 
@@ -84,7 +84,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
             rec = (int(m.group(1)) - 1) // 8
             pending = sphere(rec) if "sphere" in line else box(rec)
             continue
-        m = re.match(r"if \(spec_any_near\(.*?\)\) (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \}", line)
+        m = re.match(r"if \(spec_any_near\(.*?\)\) \{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \} \}", line)
         if m:
             tgt, op, acc = m.groups()
             if not (prune_all_far and prune_all_far(pending)):

@@ -19,10 +19,17 @@ p.add_argument("--no-balance", action="store_true")
 p.add_argument("--wpt", type=int, default=4)
 p.add_argument("--no-cull", action="store_true")
 p.add_argument("--specialize", type=int, default=2)
+p.add_argument("--prune", action="store_true", help="pruned specialised kernel; with RM_JIT_PRUNE_STATS=1 in the environment the "
+               "'refills' field becomes the number of leaves evaluated")
+p.add_argument("--refill-min", type=int, default=0)
+p.add_argument("--leaves", type=int, default=16, help="primitives of the scene (for the evaluated-leaf ratio)")
 a = p.parse_args()
 res = renderer.RayMarchingResources(0)
 res.set_option(_ffi.RM_OPT_KERNEL, a.kernel)
 res.set_option(_ffi.RM_OPT_SPECIALIZE, a.specialize)
+res.set_option(_ffi.RM_OPT_PRUNE, 1 if a.prune else 0)
+if a.refill_min:
+    res.set_option(_ffi.RM_OPT_REFILL_MIN, a.refill_min)
 res.set_option(_ffi.RM_OPT_BALANCE, 0 if a.no_balance else 1)
 res.set_option(_ffi.RM_OPT_CULL, 0 if a.no_cull else 1)
 res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, a.wpt)
@@ -49,6 +56,8 @@ print("wave duration us: mean %.1f  p50 %.1f  p90 %.1f  p99 %.1f  max %.1f" %
 print("iterations: mean %.1f p50 %d p90 %d p99 %d max %d ; sum %d" %
       (iters.mean(), np.percentile(iters, 50), np.percentile(iters, 90), np.percentile(iters, 99), iters.max(), iters.sum()))
 print("lane occupancy over iterations: %.3f ; refills/wave %.1f" % (live.sum() / max(1, iters.sum() * 64), refills.mean()))
+if a.prune and os.environ.get("RM_JIT_PRUNE_STATS"):
+    print("leaves evaluated / (iterations x leaves): %.3f" % (refills.sum() / max(1.0, float(iters.sum()) * a.leaves)))
 k = np.argsort(-end)[:8]
 for i in k:
     print("  late wave: slot %d tile %d start %.0f end %.0f dur %.0f iters %d live/iter %.1f" %
