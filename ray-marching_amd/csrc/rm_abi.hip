@@ -263,7 +263,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (spec_fn) L.spill_depth = 0u;
     const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
-                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
+                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
     if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;

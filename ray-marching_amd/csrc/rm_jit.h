@@ -118,7 +118,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     char line[512];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
+    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
     if (prune) {
         s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test

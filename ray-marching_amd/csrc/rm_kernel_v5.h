@@ -33,8 +33,20 @@ namespace rmk {
 // instantiates the kernel body with SPEC = true; the library's own build only declares it.
 //   lp: the decoded program in LDS (RmRecord[n], 8 dwords each: parameters are read at fixed offsets)
 //   thr, live: far-primitive pruning, see below
+// LdsF: an explicit LDS (address space 3) pointer.  The body hands map_scene_spec a base that went through a
+// v_mov_b32 in inline asm, so the compiler sees ONE vector register plus compile-time offsets and folds those into
+// the ds_read offset fields.  With a scalar base, ROCm 7.2's compiler materialised every record address in an SGPR
+// of its own (40 live scalars, spilled and re-read with v_readlane inside the march loop: +33 % kernel time); ROCm
+// 7.0's did not.  The laundering makes both produce the same loop.
+typedef const __attribute__((address_space(3))) float* LdsF;
+RM_DEV LdsF lds_vector_base(const void* generic_lds_ptr) {
+    const uint32_t s = (uint32_t)(__SIZE_TYPE__)(const __attribute__((address_space(3))) void*)generic_lds_ptr;
+    uint32_t v;
+    asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
+    return (LdsF)(__SIZE_TYPE__)v;  // LDS pointers are 32 bits wide; the widening only silences the host pass
+}
 template <bool FAST>
-RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval);
+RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval);
 
 // ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
 // A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
@@ -62,18 +74,18 @@ RM_DEV float map_scene_spec(const float* lp, float qx, float qy, float qz, float
 // Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned.
 constexpr float kPruneAbs = 4.0e-6f;
 RM_DEV bool spec_any_near(bool live, bool far) { return __ballot(live && !far) != 0ull; }
-RM_DEV float spec_sphere_a(const float* r, float qx, float qy, float qz) {
+RM_DEV float spec_sphere_a(LdsF r, float qx, float qy, float qz) {
     const float dx = qx - r[0], dy = qy - r[1], dz = qz - r[2];
     return (dx * dx + dy * dy) + dz * dz;  // the argument of sdf_sphere_t's sqrt, same operations
 }
-RM_DEV bool spec_sphere_far(const float* r, float a, float thrk) {
+RM_DEV bool spec_sphere_far(LdsF r, float a, float thrk) {
     const float t = thrk + r[4];
     return a > t * t;
 }
 template <bool FAST>
-RM_DEV float spec_sphere_v(const float* r, float a, SqrtGuard& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
+RM_DEV float spec_sphere_v(LdsF r, float a, SqrtGuard& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
 struct SpecBox { float qx, qy, qz, a; };
-RM_DEV SpecBox spec_box_a(const float* r, float px, float py, float pz) {
+RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
     SpecBox b;
     b.qx = __builtin_fabsf(px - r[0]) - r[3];
     b.qy = __builtin_fabsf(py - r[1]) - r[4];
@@ -89,24 +101,24 @@ RM_DEV float spec_box_v(const SpecBox& b, SqrtGuard& tiny) {
 // Leaves and the one operator with a parameter, as the generated code calls them: `r` points at the
 // record's parameters in LDS (wave-uniform address, constant offset: a broadcast read).
 template <bool FAST>
-RM_DEV float spec_sphere(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
+RM_DEV float spec_sphere(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], 0.0f, 0.0f, 0.0f};
     return sdf_sphere_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
-RM_DEV float spec_box(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
+RM_DEV float spec_box(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], r[4], r[5], 0.0f};
     return sdf_box_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
-RM_DEV float spec_cylinder(const float* r, float qx, float qy, float qz, SqrtGuard& tiny) {
+RM_DEV float spec_cylinder(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
     const float p[7] = {r[0], r[1], r[2], r[3], r[4], 0.0f, 0.0f};
     return sdf_cylinder_t<FAST>(qx, qy, qz, p, tiny);
 }
-RM_DEV float spec_plane(const float* r, float qx, float qy, float qz) {
+RM_DEV float spec_plane(LdsF r, float qx, float qy, float qz) {
     return ((qx * r[0] + qy * r[1]) + qz * r[2]) + r[3];  // as exec_command
 }
-RM_DEV float spec_smooth_union(const float* r, float a, float b) {  // as exec_command, RM_MODE_SMOOTH
+RM_DEV float spec_smooth_union(LdsF r, float a, float b) {  // as exec_command, RM_MODE_SMOOTH
     const float kk = r[0];
     float v = fmin_(a, b);
     if (kk > 0.0f) {
@@ -273,16 +285,17 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     if constexpr (PROG_IN_LDS) prog.base = lprog;
     else prog.base = L.prog;
 
+    const LdsF lprog_v = lds_vector_base(lprog);  // SPEC: the program's LDS copy, base address in a VGPR (see LdsF)
     uint32_t n_eval = 0u;  // diagnostics (pruned kernels compiled with statistics): leaves actually evaluated, per wave
     // map_scene (wgsl:187-203) at one point per lane
     auto eval_scene = [&](float x, float y, float z, float thr, bool is_live) -> float {
         float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
         SqrtGuard tiny;
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
-            v[0] = map_scene_spec<true>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny, n_eval);
+            v[0] = map_scene_spec<true>(lprog_v, x, y, z, thr, is_live, tiny, n_eval);
             if (__ballot(tiny.bad()) != 0ull) {
                 uint32_t again = 0u;
-                v[0] = map_scene_spec<false>(reinterpret_cast<const float*>(lprog), x, y, z, thr, is_live, tiny, again);
+                v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, is_live, tiny, again);
             }
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
