@@ -261,7 +261,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // structure-specialised kernel (values live in registers: no LDS spill stack)
     hipFunction_t spec_fn = lds ? specialised_kernel(c, WPT) : nullptr;
     if (spec_fn) L.spill_depth = 0u;
-    const size_t shmem = (size_t)(1024u + WPT * (4u * rmk::V5_RQ + 7u * rmk::V5_SQ)) * 4u +
+    const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
@@ -303,7 +303,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
     int wpt = c->waves_per_tile;
     const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
-    while (wpt > 1 && fixed + (size_t)wpt * ((4u * rmk::V5_RQ + 7u * rmk::V5_SQ) * 4u + (size_t)L.spill_depth * 256u) > 48u * 1024u)
+    while (wpt > 1 && fixed + (size_t)wpt * (rmk::V5_WAVE_DWORDS * 4u + (size_t)L.spill_depth * 256u) > 48u * 1024u)
         wpt /= 2;
     switch (wpt) {
     case 1: return launch_v5_w<1>(c, L, lds, n_frames, s);

@@ -129,7 +129,9 @@ RM_DEV float spec_smooth_union(LdsF r, float a, float b) {  // as exec_command, 
 }
 
 constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
-constexpr uint32_t V5_SQ = 64u;   // shade ring entries per wave
+constexpr uint32_t V5_SQ = 64u;   // miss buffer entries per wave
+constexpr uint32_t V5_HQ = 128u;  // hit buffer entries per wave (64 are taken whenever 64 are waiting)
+constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 3u * 64u;
 
 // Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
 // decoder stores each primitive's slot within its kind in RmRecord::p[6]):
@@ -246,12 +248,15 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
     float* res = reinterpret_cast<float*>(smem);                       // [1024] result code per ray (tile)
-    uint32_t* wbase = smem + POOL + wave * (4u * V5_RQ + 7u * V5_SQ);  // this wave's rings
-    uint32_t* rq_rid = wbase;                                          // ready ring (SoA)
+    uint32_t* wbase = smem + POOL + wave * V5_WAVE_DWORDS;            // this wave's buffers
+    uint32_t* rq_rid = wbase;                                          // ready rays (SoA): id, direction
     float* rq_d = reinterpret_cast<float*>(wbase + V5_RQ);             // [3][V5_RQ]
-    uint32_t* sq_rid = wbase + 4u * V5_RQ;                             // shade ring: rid | hit << 31
-    float* sq_v = reinterpret_cast<float*>(sq_rid + V5_SQ);            // [6][V5_SQ]
-    uint32_t* after = smem + POOL + WPT * (4u * V5_RQ + 7u * V5_SQ);
+    uint32_t* sq_rid = wbase + 4u * V5_RQ;                             // rays that ended without a hit: id, direction
+    float* sq_v = reinterpret_cast<float*>(sq_rid + V5_SQ);            // [3][V5_SQ]
+    uint32_t* hq_rid = sq_rid + 4u * V5_SQ;                            // hits waiting for their normal: id, position
+    float* hq_v = reinterpret_cast<float*>(hq_rid + V5_HQ);            // [3][V5_HQ]
+    float* tn = hq_v + 3u * V5_HQ;                                     // [3][64] partial normals of the running tap phase
+    uint32_t* after = smem + POOL + WPT * V5_WAVE_DWORDS;
     float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
     float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
@@ -338,178 +343,165 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float my_sx = screen_x(tx < L.W ? tx : L.W - 1u, L.W);                                   // edge tiles clamp
     const float my_sy = screen_y(rm_global_row(L, ty < L.rows ? ty : L.rows - 1u), L.H);
 
-    // lane state: evaluation point = b + d * sc
-    float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f, nx = 0.f, ny = 0.f, nz = 0.f;
-    uint32_t it = 0u, rid = 0u, mode = M_EMPTY;
-    float thr_base = __uint_as_float(0x7F800000u);  // SPEC: pruning threshold without its position term ("Pruning")
-    uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u;  // wave-uniform cursors of the ready / shade buffers
-    bool pool_open = true;                           // wave-uniform: the shared pool may still hold rays
+    // lane state of a marching ray: evaluation point = ro + d * sc
+    float dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f;
+    uint32_t it = 0u, rid = 0u, mode = M_EMPTY;  // M_EMPTY (idle), M_MARCH, M_RETIRED (nothing left to take)
+    float thr_base = inf_f;  // SPEC: pruning threshold without its position term ("Pruning")
+    // (a hit whose normal is being sampled keeps its state -- position, partial normal -- in LDS: tap phase, below)
+    uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u, hq_n = 0u;  // wave-uniform cursors: ready / miss / hit buffers
+    uint32_t tap_t = 4u, tap_n = 0u;                           // wave-uniform: tap phase step (4 = not in one), its entries
+    bool pool_open = true;                                     // wave-uniform: the shared pool may still hold rays
 
-    auto flush_shade = [&]() {  // shade every waiting entry (<= 64): one lane per entry
+    auto flush_misses = [&]() {  // floor / black for every waiting ray that ended without a hit (<= 64): wgsl:117-130
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane < sq_n) {
-            const uint32_t tag = sq_rid[lane];
-            const float a0 = sq_v[lane], a1 = sq_v[V5_SQ + lane], a2 = sq_v[2u * V5_SQ + lane];
-            float code;
-            if (tag >> 31) {  // hit: wgsl:98-103
-                code = shade_hit(a0, a1, a2, sq_v[3u * V5_SQ + lane], sq_v[4u * V5_SQ + lane], sq_v[5u * V5_SQ + lane]);
-            } else {  // marched without a hit: floor / black, wgsl:117-130
-                code = miss_code(ro, a0, a1, a2);
-            }
-            res[tag & 0x7FFFFFFFu] = code;
-        }
+        if (lane < sq_n) res[sq_rid[lane]] = miss_code(ro, sq_v[lane], sq_v[V5_SQ + lane], sq_v[2u * V5_SQ + lane]);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         sq_n = 0u;
     };
 
     for (;;) {
-        // ---- A. idle lanes take ready rays; when the buffer is empty it is refilled with the
-        //         survivors of the next 64 candidates of the pool ----
-        const unsigned long long want0 = __ballot(mode == M_EMPTY);
-        const unsigned long long live0 = __ballot(mode < M_DONE_HIT);
-        if (want0 != 0ull && (live0 == 0ull || (uint32_t)__popcll(want0) >= refill_min)) {
-            unsigned long long want = want0;
-            while (want != 0ull) {
-                if (rq_pos == rq_cnt) {  // buffer empty: produce
-                    if (!pool_open) {
-                        if (mode == M_EMPTY) mode = M_RETIRED;  // pool exhausted and buffer drained
-                        break;
+        if (tap_t == 4u) {
+            // ---- A. idle lanes take ready rays; when the buffer is empty it is refilled with the
+            //         survivors of the next 64 candidates of the pool ----
+            const unsigned long long want0 = __ballot(mode == M_EMPTY);
+            const unsigned long long live0 = __ballot(mode == M_MARCH);
+            if (want0 != 0ull && (live0 == 0ull || (uint32_t)__popcll(want0) >= refill_min)) {
+                unsigned long long want = want0;
+                while (want != 0ull) {
+                    if (rq_pos == rq_cnt) {  // buffer empty: produce
+                        if (!pool_open) {
+                            if (mode == M_EMPTY) mode = M_RETIRED;  // pool exhausted and buffer drained
+                            break;
+                        }
+                        uint32_t base = 0u;
+                        if (lane == 0u) base = atomicAdd(s_next, 64u);
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (base >= POOL) { pool_open = false; continue; }
+                        n_prod++;
+                        const uint32_t r = base + lane, s = base >> 6;
+                        float gx, gy, gz;
+                        gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
+                        const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
+                        const bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
+                                            ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+                        if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
+                        const unsigned long long keep = __ballot(!culled);
+                        if (!culled) {
+                            const uint32_t e = lane_rank(keep);
+                            rq_rid[e] = r;
+                            rq_d[e] = gx; rq_d[V5_RQ + e] = gy; rq_d[2u * V5_RQ + e] = gz;
+                        }
+                        rq_pos = 0u;
+                        rq_cnt = (uint32_t)__popcll(keep);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        continue;
                     }
-                    uint32_t base = 0u;
-                    if (lane == 0u) base = atomicAdd(s_next, 64u);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (base >= POOL) { pool_open = false; continue; }
-                    n_prod++;
-                    const uint32_t r = base + lane, s = base >> 6;
-                    float gx, gy, gz;
-                    gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
-                    const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
-                    const bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
-                                        ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
-                    if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
-                    const unsigned long long keep = __ballot(!culled);
-                    if (!culled) {
-                        const uint32_t e = lane_rank(keep);
-                        rq_rid[e] = r;
-                        rq_d[e] = gx; rq_d[V5_RQ + e] = gy; rq_d[2u * V5_RQ + e] = gz;
-                    }
-                    rq_pos = 0u;
-                    rq_cnt = (uint32_t)__popcll(keep);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    continue;
-                }
-                const uint32_t avail = rq_cnt - rq_pos, n_want = (uint32_t)__popcll(want);
-                if (mode == M_EMPTY) {
-                    const uint32_t rank = lane_rank(want);
-                    if (rank < avail) {
-                        const uint32_t e = rq_pos + rank;
-                        rid = rq_rid[e];
-                        dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
-                        bx = ro.x; by = ro.y; bz = ro.z;
-                        const bool finite_d = __builtin_fabsf(dx) < inf_f && __builtin_fabsf(dy) < inf_f && __builtin_fabsf(dz) < inf_f;
-                        if (!finite_d) {  // rd * 0 is NaN: the first step is this ray's own
-                            sc = 0.0f;    // dist (wgsl:88)
-                            it = 0u;
+                    const uint32_t avail = rq_cnt - rq_pos, n_want = (uint32_t)__popcll(want);
+                    if (mode == M_EMPTY) {
+                        const uint32_t rank = lane_rank(want);
+                        if (rank < avail) {
+                            const uint32_t e = rq_pos + rank;
+                            rid = rq_rid[e];
+                            dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
+                            const bool finite_d = __builtin_fabsf(dx) < inf_f && __builtin_fabsf(dy) < inf_f && __builtin_fabsf(dz) < inf_f;
+                            // The shared first step applies to finite rd that neither hit nor ended there (START_MARCH);
+                            // everything else takes its own first step: rd * 0 = NaN, or the hit at ro (rare: the camera
+                            // inside a solid), which then goes through the ordinary hit path.
+                            const bool shared = finite_d && start == START_MARCH;
+                            sc = shared ? 0.0f + f0 : 0.0f;  // dist (wgsl:88), dist += scene_dist (wgsl:114)
+                            it = shared ? 1u : 0u;
+                            thr_base = shared ? __builtin_fabsf(f0) * 2.00002f : inf_f;
                             mode = M_MARCH;
-                            thr_base = inf_f;  // nothing is known yet
-                        } else if (start == START_HIT) {  // as the hit branch below, at pos = ro
-                            sc = eps;
-                            uint32_t sx, sy, sz;
-                            tap_signs(0u, sx, sy, sz);
-                            dx = __uint_as_float(0x3F800000u ^ sx);
-                            dy = __uint_as_float(0x3F800000u ^ sy);
-                            dz = __uint_as_float(0x3F800000u ^ sz);
-                            it = 0u;
-                            mode = M_TAP0;
-                            thr_base = __builtin_fabsf(f0) * 1.00001f + 1.75e-4f;
-                        } else {  // START_MARCH (START_DONE rays never get here)
-                            sc = 0.0f + f0;  // dist += scene_dist (wgsl:114)
-                            it = 1u;
-                            mode = M_MARCH;
-                            thr_base = __builtin_fabsf(f0) * 2.00002f;
                         }
                     }
+                    rq_pos += n_want < avail ? n_want : avail;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    want = __ballot(mode == M_EMPTY);
                 }
-                rq_pos += n_want < avail ? n_want : avail;
+            }
+            // ---- hits waiting for their normal: a tap phase runs when 64 are waiting, or when nothing else is left ----
+            const bool any_live = __ballot(mode == M_MARCH) != 0ull;
+            if (!any_live && __ballot(mode == M_EMPTY) != 0ull) continue;  // idle lanes remain: force a refill round
+            if (hq_n >= 64u || (!any_live && hq_n != 0u)) {
+                tap_n = hq_n < 64u ? hq_n : 64u;
+                hq_n -= tap_n;  // the most recent tap_n entries: [hq_n, hq_n + tap_n); nothing is pushed during the phase
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                want = __ballot(mode == M_EMPTY);
+                tap_t = 0u;
+            } else if (!any_live) {
+                break;  // every lane retired, nothing waiting
             }
         }
-        const unsigned long long live = __ballot(mode < M_DONE_HIT);
-        if (live == 0ull) {
-            if (__ballot(mode == M_EMPTY) == 0ull) break;  // every lane retired
-            continue;                                       // idle lanes remain: force a refill round
-        }
+        const bool tapping = tap_t < 4u;  // wave-uniform
 
-        // ---- B. one map_scene evaluation per live lane ----
+        // ---- B. one map_scene evaluation: a march step of every live ray, or normal tap tap_t of every waiting hit ----
+        float ex, ey, ez, thr = inf_f;
+        bool is_live;
+        uint32_t sgx = 0u, sgy = 0u, sgz = 0u;
+        const uint32_t he = hq_n + lane;  // this lane's hit-buffer entry in a tap phase (< V5_HQ for every lane)
+        if (tapping) {  // pos + k_t * eps (wgsl:138-141); k_t * eps = +-eps exactly
+            tap_signs(tap_t, sgx, sgy, sgz);
+            ex = hq_v[he] + __uint_as_float(__float_as_uint(eps) ^ sgx);
+            ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
+            ez = hq_v[2u * V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgz);
+            is_live = lane < tap_n;
+        } else {
+            ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
+            is_live = mode == M_MARCH;
+            if constexpr (SPEC) thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+        }
         n_iter++;
-        n_live += (uint32_t)__popcll(live);
-        uint32_t fin = 0u;  // 1: finished with a hit, 2: finished without
-        {
-            float qx[1], qy[1], qz[1];
-            qx[0] = bx + dx * sc; qy[0] = by + dy * sc; qz[0] = bz + dz * sc;  // wgsl:91 / :138-141
-            float thr = inf_f;
-            if constexpr (SPEC) thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(qx[0]) + __builtin_fabsf(qy[0])) + __builtin_fabsf(qz[0])));
-            const float sd = eval_scene(qx[0], qy[0], qz[0], thr, mode < M_DONE_HIT);
-            if (mode == M_MARCH) {
-                if (sd < L.min_dist) {  // wgsl:97: hit -> normal taps around pos = q
-                    bx = qx[0]; by = qy[0]; bz = qz[0];
-                    sc = eps;
-                    uint32_t sx, sy, sz;
-                    tap_signs(0u, sx, sy, sz);
-                    dx = __uint_as_float(0x3F800000u ^ sx);
-                    dy = __uint_as_float(0x3F800000u ^ sy);
-                    dz = __uint_as_float(0x3F800000u ^ sz);
-                    mode = M_TAP0;
-                    if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 1.00001f + 1.75e-4f;  // all four taps: |q - q_hit| = eps sqrt(3)
-                } else if (sd > L.max_dist) {  // wgsl:109-111
-                    fin = 2u;
-                } else {
-                    sc += sd;  // wgsl:114
-                    if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 2.00002f;  // the next point is |sd| |rd| away
-                    it += 1u;
-                    if (it >= L.max_iter) fin = 2u;  // loop bound, wgsl:90
-                }
-            } else if (mode < M_DONE_HIT) {
-                const uint32_t t = mode - M_TAP0;  // tap t: n (+)= k_t * f; products with +-1 are exact
-                uint32_t sx, sy, sz;
-                tap_signs(t, sx, sy, sz);
-                const float vx = __uint_as_float(__float_as_uint(sd) ^ sx);
-                const float vy = __uint_as_float(__float_as_uint(sd) ^ sy);
-                const float vz = __uint_as_float(__float_as_uint(sd) ^ sz);
-                nx = t == 0u ? vx : nx + vx;
-                ny = t == 0u ? vy : ny + vy;
-                nz = t == 0u ? vz : nz + vz;
-                tap_signs(t + 1u, sx, sy, sz);
-                dx = __uint_as_float(0x3F800000u ^ sx);
-                dy = __uint_as_float(0x3F800000u ^ sy);
-                dz = __uint_as_float(0x3F800000u ^ sz);
-                mode += 1u;
-                if (mode == M_DONE_HIT) fin = 1u;
+        n_live += (uint32_t)__popcll(__ballot(is_live));
+        const float sd = eval_scene(ex, ey, ez, thr, is_live);
+
+        if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
+            const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
+            const float vy = __uint_as_float(__float_as_uint(sd) ^ sgy);
+            const float vz = __uint_as_float(__float_as_uint(sd) ^ sgz);
+            // the partial sum waits in LDS between taps, not in three registers that every march iteration would carry
+            const float nx = tap_t == 0u ? vx : tn[lane] + vx;
+            const float ny = tap_t == 0u ? vy : tn[64u + lane] + vy;
+            const float nz = tap_t == 0u ? vz : tn[128u + lane] + vz;
+            if (++tap_t == 4u) {
+                if (is_live) res[hq_rid[he]] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
+            } else {
+                tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
             }
+            continue;
         }
 
-        // ---- C. finished rays -> shade ring; the lane becomes idle ----
-        const unsigned long long fin_mask = __ballot(fin != 0u);
-        if (fin_mask != 0ull) {
-            const uint32_t n_fin = (uint32_t)__popcll(fin_mask);
-            if (sq_n + n_fin > V5_SQ) flush_shade();
-            if (fin != 0u) {
-                const uint32_t e = sq_n + lane_rank(fin_mask);
-                if (fin == 1u) {
-                    sq_rid[e] = rid | 0x80000000u;
-                    sq_v[e] = nx; sq_v[V5_SQ + e] = ny; sq_v[2u * V5_SQ + e] = nz;
-                    sq_v[3u * V5_SQ + e] = bx; sq_v[4u * V5_SQ + e] = by; sq_v[5u * V5_SQ + e] = bz;
-                } else {
-                    sq_rid[e] = rid;
-                    sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
-                }
+        // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
+        const bool hit = is_live && sd < L.min_dist;                // wgsl:97
+        const bool esc = is_live && !hit && sd > L.max_dist;        // wgsl:109-111
+        const bool go = is_live && !hit && !esc;
+        if (go) {
+            sc += sd;  // wgsl:114
+            it += 1u;
+            if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 2.00002f;  // the next point is |sd| |rd| away
+        }
+        const bool miss = esc || (go && it >= L.max_iter);          // loop bound, wgsl:90
+        const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+        if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
+            if (hit) {
+                const uint32_t e = hq_n + lane_rank(hit_mask);
+                hq_rid[e] = rid;
+                hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
                 mode = M_EMPTY;
             }
-            sq_n += n_fin;
+            hq_n += (uint32_t)__popcll(hit_mask);
+        }
+        if (miss_mask != 0ull) {
+            const uint32_t n_miss = (uint32_t)__popcll(miss_mask);
+            if (sq_n + n_miss > V5_SQ) flush_misses();
+            if (miss) {
+                const uint32_t e = sq_n + lane_rank(miss_mask);
+                sq_rid[e] = rid;
+                sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
+                mode = M_EMPTY;
+            }
+            sq_n += n_miss;
         }
     }
-    if (sq_n != 0u) flush_shade();
+    if (sq_n != 0u) flush_misses();
     __syncthreads();  // all waves of the tile are done: res[] is complete
 
     // ---- resolve: one pixel per thread, samples in the reference order (wgsl:44-45, 68-69) ----
