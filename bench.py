@@ -51,6 +51,7 @@ def parse():
                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-ab", action="store_true", help="skip the interpreter-kernel A/B leg that follows the timed region")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
     return p.parse_args()
 
@@ -197,6 +198,28 @@ def main():
         elapsed, kernel_ms, draw_ms = float(t[0]), float(t[1]), float(t[2])
 
     checksum = float(out[..., :3].double().sum().item())    # touches the result: nothing was skipped
+
+    # A/B leg (N = 1 only, after the timed region): the same frames through the interpreter kernel, i.e. the design
+    # north_star spells out (node array staged in LDS and INTERPRETED); reported beside the default path's number
+    ab = None
+    if world == 1 and specialized and not args.no_ab:
+        res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
+        for s in range(args.warmup):
+            draw()
+        res.set_option(_ffi.RM_OPT_TIMING, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            res.set_uniforms(unis[args.warmup + k])
+            draw()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ab_checksum = float(out[..., :3].double().sum().item())
+        ab = {"kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine)",
+              "value": W * H * args.steps / dt / 1e6, "unit": "Mpixels/s", "kernel_ms": res.info(_ffi.RM_INFO_KERNEL_MS),
+              "same_image": ab_checksum == checksum}
+        res.set_option(_ffi.RM_OPT_TIMING, 0)
+        res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
     if rank == 0:
         pixels = W * H * args.steps * (1 if tile else world)
         value = pixels / elapsed / 1e6
@@ -232,6 +255,8 @@ def main():
                                  "bound by ~3 orders of magnitude, see `compute`"},
             "checksum_rgb": checksum,
         }
+        if ab is not None:
+            line["ab_interpreter_kernel"] = ab
         if world == 1 and not args.no_cpu_baseline:
             base, cnt, (cw, ch) = cpu_baseline(args, (cc, words), still_events)
             line["cpu_baseline"] = base
