@@ -101,6 +101,9 @@ enum rm_option {
     RM_OPT_BALANCE = 5,    /* v3 kernels: 1 (default) = cost pre-pass + heaviest-tile-first dispatch order */
     RM_OPT_WAVES_PER_TILE = 7, /* v3 kernels: waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
     RM_OPT_WAVE_STATS = 6, /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
+    RM_OPT_OUTPUT_FORMAT = 10, /* enum rm_format: what rm_draw / rm_draw_strips / rm_draw_batch write (default RM_FORMAT_RGBA32F).
+                                  The 8-bit formats are the output stage of SURVEY 8(f)-3: the reference's own colour target is
+                                  the 8-bit egui surface (renderer.rs:113).  Only the default (v5) kernels implement them. */
     RM_OPT_PRUNE = 9,      /* specialised kernels: 1 = skip, per wave and per march step, primitives that provably cannot
                               influence the scene value there (exact; DESIGN.md "Pruning").  Default 0: on MI355X the
                               wave-uniform tests cost more than the skipped work saves (measured) */
@@ -110,6 +113,14 @@ enum rm_option {
                               0 = never; 1 (default) = compile on a background thread, draw with the interpreter kernel
                               until the compiled one is ready; 2 = the first draw of a new structure waits for the compiler.
                               Without libhiprtc, or if compilation fails, the interpreter kernel keeps drawing. */
+};
+/* Pixel formats of the output image (row-major, top row first).  The 8-bit formats quantise the RGBA32F value the
+ * shader returns (wgsl:73-75) the way a UNORM colour target does: clamp to [0,1] (NaN -> 0), times 255, round to nearest
+ * even; alpha is 255.  "out_rgba" pointers then address 4 bytes per pixel instead of 16. */
+enum rm_format {
+    RM_FORMAT_RGBA32F = 0,      /* 16 B/pixel: r, g, b, a as binary32 */
+    RM_FORMAT_RGBA8_UNORM = 1,  /* 4 B/pixel: bytes r, g, b, a */
+    RM_FORMAT_BGRA8_UNORM = 2   /* 4 B/pixel: bytes b, g, r, a (wgpu's usual surface format) */
 };
 enum rm_kernel {
     RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */

@@ -64,6 +64,8 @@ def lib():
         L.rmo_render.restype = C.c_int
         L.rmo_render_mt.argtypes = L.rmo_render.argtypes + [u32]
         L.rmo_render_mt.restype = C.c_int
+        L.rmo_quantize_unorm8.argtypes = [f32p, C.c_uint64, C.c_int, C.POINTER(C.c_uint8)]
+        L.rmo_quantize_unorm8.restype = None
         L.rmo_builder_new.restype = C.c_void_p
         L.rmo_builder_free.argtypes = [C.c_void_p]
         L.rmo_builder_cmd_count.argtypes = [C.c_void_p]
@@ -194,3 +196,11 @@ def render(u, limits, cmd_count, words, W, H, row0=0, rows=None, threads=1, want
     if rc != 0:
         raise ValueError("oracle rejected program: rc=%d" % rc)
     return (out, cnt.as_dict()) if want_counters else out
+
+
+def quantize_unorm8(img, bgra=False):
+    """RGBA32F (..., 4) -> uint8 (..., 4) as an 8-bit UNORM colour target stores it (clamp, * 255, round to nearest even)."""
+    a = np.ascontiguousarray(np.asarray(img, dtype=np.float32))
+    out = np.empty(a.shape, dtype=np.uint8)
+    lib().rmo_quantize_unorm8(_f32p(a), a.size // 4, int(bool(bgra)), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out

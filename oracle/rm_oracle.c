@@ -687,5 +687,23 @@ RMO_API int rmo_prepare_uniforms(float vw, float vh, const float* position3, con
     return rmo_camera_inv_view(position3, quat4, u->inv_view) ? RMO_OK : RMO_ERR_NULL;
 }
 
+/* Output stage (extension; the reference's colour target is the 8-bit egui surface, renderer.rs:113).
+ * UNORM8 quantisation of RGBA32F pixels as a colour target performs it: clamp to [0,1] (NaN -> 0), times 255, round
+ * to nearest even.  out: 4 bytes per pixel, r g b a (bgra = 0) or b g r a (bgra = 1); alpha = 255 for the 1.0 of
+ * wgsl:75.  Which rounding a real wgpu backend applies is not pinned by anything in the reference: parity unpinned. */
+RMO_API void rmo_quantize_unorm8(const float* rgba, uint64_t n_pixels, int bgra, uint8_t* out) {
+    for (uint64_t i = 0; i < n_pixels; i++) {
+        uint8_t q[4];
+        for (int k = 0; k < 4; k++) {
+            float x = rmo_min(rmo_max(rgba[4 * i + k], 0.0f), 1.0f) * 255.0f;
+            q[k] = (uint8_t)rmo_f2i(rintf(x));
+        }
+        out[4 * i + 0] = bgra ? q[2] : q[0];
+        out[4 * i + 1] = q[1];
+        out[4 * i + 2] = bgra ? q[0] : q[2];
+        out[4 * i + 3] = q[3];
+    }
+}
+
 RMO_API uint32_t rmo_sizeof_uniforms(void) { return (uint32_t)sizeof(rmo_uniforms); }
 RMO_API uint32_t rmo_sizeof_limits(void) { return (uint32_t)sizeof(rmo_limits); }

@@ -38,6 +38,8 @@ RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
 RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
 RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
 RM_JIT_PRUNE = 0x100
+RM_OPT_OUTPUT_FORMAT = 10
+RM_FORMAT_RGBA32F, RM_FORMAT_RGBA8_UNORM, RM_FORMAT_BGRA8_UNORM = 0, 1, 2
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT, RM_INFO_SPECIALIZED, RM_INFO_JIT_STATE, RM_INFO_JIT_COMPILE_MS = 4, 5, 6, 7, 8
 

@@ -77,6 +77,7 @@ struct rm_ctx {
     // structure specialisation (rm_jit.h): 0 off, 1 compile in the background and switch over when
     // ready, 2 wait for the compiler at the first draw of a new structure
     int specialize = 1;
+    int out_format = RM_FORMAT_RGBA32F;  // RM_OPT_OUTPUT_FORMAT
     bool prune = false;  // RM_OPT_PRUNE: far-primitive pruning in specialised kernels (measured slower: off)
     uint64_t prog_gen = 0;  // bumped whenever the decoded program changes
     std::shared_ptr<rmjit::Entry> spec;
@@ -354,6 +355,9 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.max_iter = c->limits.max_iter;
     L.W = W; L.H = H; L.row0 = row0; L.rows = rows;
     L.out = d_out;
+    L.out_format = (uint32_t)c->out_format;
+    if (c->out_format != RM_FORMAT_RGBA32F && !(c->kernel == RM_KERNEL_DEFAULT || c->kernel == RM_KERNEL_V5 || c->kernel == RM_KERNEL_V5_LDS))
+        return fail(c, RM_ERR_ARG, "kernel variant %d writes RGBA32F only (8-bit output formats need the default kernels)", c->kernel);
     L.frames = frames_dev;
     L.order = nullptr;
     L.stats = nullptr;
@@ -448,6 +452,8 @@ int check_limits(rm_ctx* c) {
         return fail(c, RM_ERR_RANGE, "max_iter %u exceeds the supported maximum %u", c->limits.max_iter, kMaxIter);
     return RM_OK;
 }
+
+size_t pixel_bytes(const rm_ctx* c) { return c->out_format == RM_FORMAT_RGBA32F ? 16u : 4u; }
 
 int ensure_out(rm_ctx* c, size_t bytes) {
     if (bytes <= c->d_out_bytes) return RM_OK;
@@ -603,7 +609,7 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
-    const size_t bytes = (size_t)rows * W * 16u;
+    const size_t bytes = (size_t)rows * W * pixel_bytes(c);
     if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, static_cast<hipStream_t>(stream));
     hipStream_t s = c->stream;
     rc = ensure_out(c, bytes);
@@ -646,7 +652,7 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     if (rc != RM_OK) return rc;
     StripSpec sp;
     sp.rows = strip_rows; sp.first = first; sp.stride = stride;
-    const size_t bytes = (size_t)rows * W * 16u;
+    const size_t bytes = (size_t)rows * W * pixel_bytes(c);
     if (out_is_device) return launch(c, nullptr, 1, W, H, 0, rows, out_rgba, static_cast<hipStream_t>(stream), sp);
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
@@ -678,7 +684,7 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
         c->d_frames_cap = n_frames;
     }
     HIP_TRY(c, hipMemcpy(c->d_frames, frames, (size_t)n_frames * sizeof(rm_uniforms), hipMemcpyHostToDevice));
-    const size_t bytes = (size_t)n_frames * H * W * 16u;
+    const size_t bytes = (size_t)n_frames * H * W * pixel_bytes(c);
     if (out_is_device) return launch(c, c->d_frames, n_frames, W, H, 0, H, out_rgba, s);
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
@@ -709,6 +715,10 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
     case RM_OPT_PRUNE: c->prune = value != 0; c->spec_gen = ~0ull; return RM_OK;
+    case RM_OPT_OUTPUT_FORMAT:
+        if (value < RM_FORMAT_RGBA32F || value > RM_FORMAT_BGRA8_UNORM) return fail(c, RM_ERR_ARG, "unknown output format %lld", (long long)value);
+        c->out_format = (int)value;
+        return RM_OK;
     case RM_OPT_SPECIALIZE:
         if (value < 0 || value > 2) return fail(c, RM_ERR_ARG, "RM_OPT_SPECIALIZE: %lld is not 0, 1 or 2", (long long)value);
         c->specialize = (int)value;

@@ -56,7 +56,8 @@ struct RmLaunch {
     // Interleaved strips (multi-GPU tiling): when strip_rows != 0 the `rows` output rows are the
     // concatenation of strips strip_first, strip_first + strip_stride, ... of strip_rows rows each.
     uint32_t strip_rows, strip_first, strip_stride;
-    float* out;                // rows*W*4 floats per frame
+    float* out;                // rows*W pixels per frame: 16 B each (RM_FORMAT_RGBA32F) or 4 B each (8-bit formats)
+    uint32_t out_format;       // enum rm_format
     unsigned long long* stats; // diagnostics (RM_OPT_WAVE_STATS): 4 x u64 per wave, or nullptr
     const uint32_t* order;     // nullptr: tiles in raster order; else dispatch slot -> tile id, per frame
     const rm_uniforms* frames; // nullptr: use `u`; else frames[blockIdx.z]

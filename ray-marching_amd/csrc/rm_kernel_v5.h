@@ -268,7 +268,6 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 
     rm_uniforms u = L.u;
     if (L.frames) u = L.frames[blockIdx.z];  // wave-uniform
-    float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
     const uint32_t tiles_x = (L.W + 7u) / 8u;
     const uint32_t* order = work.order + (size_t)blockIdx.z * n_tiles;
     uint32_t* counters = work.counters + 4u * blockIdx.z;
@@ -525,9 +524,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 tg += __builtin_sqrtf(cg);
                 tb += __builtin_sqrtf(cb);
             }
-            float4 o;
-            o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
-            reinterpret_cast<float4*>(out)[(size_t)py * L.W + px] = o;
+            store_pixel(L, blockIdx.z, (size_t)py * L.W + px, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75
         }
     }
     __syncthreads();  // res[] / rings / cursor are reused by the next tile
@@ -634,7 +631,6 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     rm_uniforms u = L.u;
     if (L.frames) u = L.frames[blockIdx.z];
-    float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
     const bool tables = (L.flags & 1u) != 0u;
     if (tid == 0u) *s_veto = 0u;
@@ -691,9 +687,7 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
         tb += __builtin_sqrtf(cb);
     }
     if (tx < L.W && ty < L.rows) {
-        float4 o;
-        o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
-        reinterpret_cast<float4*>(out)[(size_t)ty * L.W + tx] = o;
+        store_pixel(L, blockIdx.z, (size_t)ty * L.W + tx, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75
     }
 }
 #endif

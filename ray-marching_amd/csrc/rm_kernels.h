@@ -88,6 +88,23 @@ RM_DEV int shade_floor(float oy, float ox, float oz, float dx, float dy, float d
     return -1;
 }
 
+// ---- output stage -------------------------------------------------------------------------
+// UNORM8 quantisation of one channel as a colour target does it: clamp (NaN -> 0), * 255, round to nearest even.
+RM_DEV uint32_t unorm8(float x) { return (uint32_t)__float2int_rn(fmin_(fmax_(x, 0.0f), 1.0f) * 255.0f); }
+// Pixel `index` (within the frame that starts `frame` frames into L.out) = (r, g, b, 1).
+RM_DEV void store_pixel(const RmLaunch& L, uint32_t frame, size_t index, float r, float g, float b) {
+    const size_t at = (size_t)frame * L.rows * L.W + index;
+    if (L.out_format == RM_FORMAT_RGBA32F) {
+        float4 o;
+        o.x = r; o.y = g; o.z = b; o.w = 1.0f;  // wgsl:73-75
+        reinterpret_cast<float4*>(L.out)[at] = o;
+    } else {
+        const uint32_t qr = unorm8(r), qg = unorm8(g), qb = unorm8(b);
+        const uint32_t lo = L.out_format == RM_FORMAT_BGRA8_UNORM ? qb : qr, hi = L.out_format == RM_FORMAT_BGRA8_UNORM ? qr : qb;
+        reinterpret_cast<uint32_t*>(L.out)[at] = lo | (qg << 8) | (hi << 16) | 0xFF000000u;
+    }
+}
+
 // ---- program access policies -------------------------------------------------------------
 // LDS: the decoded program was staged into shared memory by the workgroup; every lane reads
 // the same address (broadcast), the opcode is made scalar with readfirstlane.

@@ -1,0 +1,188 @@
+"""Offline camera-orbit batch (BASELINE config 5): N frames of one scene, frame f at
+yaw = 2*pi*f/N, sharded over the ranks of one node (frame f -> rank f % world, no collective), written as binary PPM.
+
+  output stage   frames are rendered in an 8-bit format (4 B/pixel on the device and over PCIe, a quarter of RGBA32F);
+                 the RGBA32F path stays available (--format f32 writes raw little-endian float32 RGBA, .rgba32f)
+  async drain    a ring of device buffers and pinned host buffers per rank: frame i+1 renders while frame i is copied
+                 to the host on a second stream and writer threads turn the previous ones into files
+  resume         a frame whose file already exists with the exact expected size is skipped; files are written to a
+                 temporary name and renamed, so an interrupted run never leaves a plausible-looking partial frame
+
+The reference has no offline mode (it only draws into an eframe window, main.rs:14-19); this is the batch driver
+the north-star configuration asks for, built on the same rm_draw entry point the window path uses.
+
+  python -m ray_marching_amd.orbit_batch --out-dir /tmp/orbit --frames 1024 --width 3840 --height 2160
+  python -m torch.distributed.run --nproc-per-node 8 ... -m ray_marching_amd.orbit_batch ...    (one rank per GPU)
+"""
+import argparse
+import json
+import math
+import os
+import queue
+import threading
+import time
+
+import numpy as np
+
+from . import shard
+
+
+def frame_path(out_dir, f, fmt):
+    return os.path.join(out_dir, "frame_%05d.%s" % (f, "ppm" if fmt != "f32" else "rgba32f"))
+
+
+def ppm_header(W, H):
+    return b"P6\n%d %d\n255\n" % (W, H)
+
+
+def expected_size(W, H, fmt):
+    return len(ppm_header(W, H)) + W * H * 3 if fmt != "f32" else W * H * 16
+
+
+def frames_todo(out_dir, n_frames, rank, world, W, H, fmt):
+    """This rank's frames that still have to be rendered (resume by frame index)."""
+    want = expected_size(W, H, fmt)
+    todo = []
+    for f in shard.frames_of_rank(n_frames, rank, world):
+        p = frame_path(out_dir, f, fmt)
+        try:
+            if os.path.getsize(p) == want:
+                continue
+        except OSError:
+            pass
+        todo.append(f)
+    return todo
+
+
+def write_frame(out_dir, f, img, fmt):
+    """img: (H, W, 4) uint8 in RGBA order, or float32 for fmt == 'f32'.  Atomic: temp file + rename."""
+    p = frame_path(out_dir, f, fmt)
+    tmp = p + ".part"
+    with open(tmp, "wb") as fh:
+        if fmt == "f32":
+            fh.write(np.ascontiguousarray(img, dtype=np.float32).tobytes())
+        else:
+            H, W = img.shape[:2]
+            fh.write(ppm_header(W, H))
+            fh.write(np.ascontiguousarray(img[..., :3]).tobytes())
+    os.replace(tmp, p)
+    return p
+
+
+def orbit_yaw(f, n_frames):
+    return 2.0 * math.pi * f / n_frames
+
+
+def render_batch(args, rank=0, world=1, device=0, log=None):
+    """Renders this rank's missing frames.  Returns a summary dict."""
+    import torch
+    from . import _ffi, camera, csg, renderer
+
+    W, H = args.width, args.height
+    os.makedirs(args.out_dir, exist_ok=True)
+    todo = frames_todo(args.out_dir, args.frames, rank, world, W, H, args.format)
+    mine = len(shard.frames_of_rank(args.frames, rank, world))
+    summary = {"rank": rank, "frames_assigned": mine, "frames_skipped": mine - len(todo), "frames_rendered": 0,
+               "seconds": 0.0}
+    if not todo:
+        return summary
+    torch.cuda.set_device(device)
+    res = renderer.RayMarchingResources(device)
+    res.set_option(_ffi.RM_OPT_SPECIALIZE, 2)       # static scene: compile its kernel once, before the first frame
+    res.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
+    node = csg.scene(args.scene)
+    cc, words = csg.serialize(node)
+    if len(words) > 255:
+        res.resize_command_buffer(4 * (len(words) + 1 + 63) // 64 * 64)
+    res.set_program(cc, words)
+    f32 = args.format == "f32"
+    res.set_output_format(_ffi.RM_FORMAT_RGBA32F if f32 else _ffi.RM_FORMAT_RGBA8_UNORM)
+    dt = torch.float32 if f32 else torch.uint8
+    n_slots, n_writers = max(2, args.slots), max(1, args.writers)
+    dev = [torch.empty((H, W, 4), dtype=dt, device="cuda") for _ in range(n_slots)]
+    host = [torch.empty((H, W, 4), dtype=dt).pin_memory() for _ in range(n_slots)]
+    render_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
+    rendered = [torch.cuda.Event() for _ in range(n_slots)]
+    copied = [torch.cuda.Event() for _ in range(n_slots)]
+    free = [threading.Semaphore(1) for _ in range(n_slots)]       # host[slot] may be overwritten
+    jobs = queue.Queue()
+    errors = []
+
+    def writer():
+        while True:
+            job = jobs.get()
+            if job is None:
+                return
+            f, slot = job
+            try:
+                copied[slot].synchronize()
+                write_frame(args.out_dir, f, host[slot].numpy(), args.format)
+            except Exception as e:      # surfaced by the main thread
+                errors.append(e)
+            finally:
+                free[slot].release()
+
+    threads = [threading.Thread(target=writer, daemon=True) for _ in range(n_writers)]
+    for th in threads:
+        th.start()
+    ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
+    t0 = time.perf_counter()
+    for i, f in enumerate(todo):
+        slot = i % n_slots
+        free[slot].acquire()            # the writer is done with host[slot] (and so is the copy into it)
+        if errors:
+            break
+        ctl.set_angles(orbit_yaw(f, args.frames), -0.25, 5.0)
+        res.set_uniforms(renderer.prepare_uniforms((float(W), float(H)), ctl.camera()))
+        render_s.wait_event(copied[slot])          # dev[slot] was read by the copy n_slots frames ago
+        res.draw_device(W, H, dev[slot].data_ptr(), stream=render_s.cuda_stream)
+        rendered[slot].record(render_s)
+        copy_s.wait_event(rendered[slot])
+        with torch.cuda.stream(copy_s):
+            host[slot].copy_(dev[slot], non_blocking=True)
+        copied[slot].record(copy_s)
+        jobs.put((f, slot))
+        summary["frames_rendered"] += 1
+        if log and (i + 1) % 64 == 0:
+            log("rank %d: %d / %d frames" % (rank, i + 1, len(todo)))
+    for _ in threads:
+        jobs.put(None)
+    for th in threads:
+        th.join()
+    torch.cuda.synchronize()
+    summary["seconds"] = time.perf_counter() - t0
+    res.close()
+    if errors:
+        raise errors[0]
+    return summary
+
+
+def parse(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    p.add_argument("--out-dir", required=True)
+    p.add_argument("--frames", type=int, default=1024)
+    p.add_argument("--width", type=int, default=3840)
+    p.add_argument("--height", type=int, default=2160)
+    p.add_argument("--scene", default="g32")
+    p.add_argument("--max-iter", type=int, default=256)
+    p.add_argument("--format", choices=["ppm", "f32"], default="ppm", help="ppm: 8-bit output stage; f32: raw RGBA32F")
+    p.add_argument("--slots", type=int, default=4, help="device / pinned-host buffer pairs in flight")
+    p.add_argument("--writers", type=int, default=3, help="file-writer threads")
+    return p.parse_args(argv)
+
+
+def main(argv=None):
+    args = parse(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    s = render_batch(args, rank, world, local_rank, log=lambda m: print(m, flush=True))
+    s["Mpixels_per_s"] = s["frames_rendered"] * args.width * args.height / s["seconds"] / 1e6 if s["seconds"] else 0.0
+    s["frames_per_s"] = s["frames_rendered"] / s["seconds"] if s["seconds"] else 0.0
+    s["config"] = "%d frames %dx%d %s %d steps, format %s, frame f -> rank f %% %d" % (
+        args.frames, args.width, args.height, args.scene, args.max_iter, args.format, world)
+    print(json.dumps(s), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,7 @@ class RayMarchingResources:
             raise _ffi.RmError(rc, (self._L.rm_last_error(None) or b"").decode())
         self._h = h
         self.device = int(device)
+        self._dtype = np.float32
 
     def close(self):
         if getattr(self, "_h", None):
@@ -77,10 +78,16 @@ class RayMarchingResources:
         self._check(self._L.rm_validate(self._h))
 
     # -- draws -------------------------------------------------------------------------------
+    def set_output_format(self, fmt):
+        """RM_OPT_OUTPUT_FORMAT: _ffi.RM_FORMAT_RGBA32F (default) / RGBA8_UNORM / BGRA8_UNORM.  The host-array draw
+        methods then return uint8 (..., 4) arrays; the *_device methods write 4 bytes per pixel."""
+        self.set_option(_ffi.RM_OPT_OUTPUT_FORMAT, fmt)
+        self._dtype = np.float32 if fmt == _ffi.RM_FORMAT_RGBA32F else np.uint8
+
     def draw(self, W, H, row0=0, rows=None):
-        """Render rows [row0,row0+rows) into a new host array (rows, W, 4) float32."""
+        """Render rows [row0,row0+rows) into a new host array (rows, W, 4): float32, or uint8 for the 8-bit formats."""
         rows = H - row0 if rows is None else rows
-        out = np.empty((max(rows, 0), W, 4), dtype=np.float32)
+        out = np.empty((max(rows, 0), W, 4), dtype=self._dtype)
         self._check(self._L.rm_draw(self._h, W, H, row0, rows, out.ctypes.data_as(C.c_void_p), 0, None))
         return out
 
@@ -94,7 +101,7 @@ class RayMarchingResources:
         """This GPU's interleaved strips of a W x H image (rm_draw_strips) -> (rows, W, 4) host array."""
         from . import shard
         rows = shard.strip_row_count(H, strip_rows, first, stride)
-        out = np.empty((rows, W, 4), dtype=np.float32)
+        out = np.empty((rows, W, 4), dtype=self._dtype)
         n = C.c_uint32(0)
         self._check(self._L.rm_draw_strips(self._h, W, H, strip_rows, first, stride,
                                            out.ctypes.data_as(C.c_void_p) if rows else None, 0, None, C.byref(n)))
@@ -109,7 +116,7 @@ class RayMarchingResources:
 
     def draw_batch(self, frames, W, H):
         arr = (Uniforms * len(frames))(*frames)
-        out = np.empty((len(frames), H, W, 4), dtype=np.float32)
+        out = np.empty((len(frames), H, W, 4), dtype=self._dtype)
         self._check(self._L.rm_draw_batch(self._h, arr, len(frames), W, H, out.ctypes.data_as(C.c_void_p), 0, None))
         return out
 

@@ -548,3 +548,54 @@ def test_host_output_rate_is_reported(res, oracle):
     dt = (time.perf_counter() - t0) / 5
     print("host-destination draw 1920x1080: %.2f ms = %.0f Mpixels/s (PCIe + pageable-host copy included)" % (dt * 1e3, W * H / dt / 1e6))
     assert img.shape == (H, W, 4)
+
+
+@pytest.mark.parametrize("fmt,bgra", [(_ffi.RM_FORMAT_RGBA8_UNORM, False), (_ffi.RM_FORMAT_BGRA8_UNORM, True)], ids=["rgba8", "bgra8"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5_lds", "v5_spec"])
+def test_8bit_output_formats(res, oracle, fmt, bgra, kernel):
+    """Output stage: the 8-bit image is the UNORM8 quantisation of the RGBA32F image, byte for byte --
+    single draws (ragged sizes, row bands), interleaved strips and batches, culled and marched tiles alike."""
+    try:
+        for W, H in [(64, 48), (37, 21)]:
+            cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+            lim = (0.01, 100.0, 96)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            ref = oracle.quantize_unorm8(oracle.render(u, lim, cc, w, W, H, threads=4), bgra=bgra)
+            res.set_output_format(fmt)
+            img = res.draw(W, H)
+            assert img.dtype == np.uint8 and img.shape == (H, W, 4)
+            assert img.tobytes() == ref.tobytes()
+            band = res.draw(W, H, row0=8, rows=9)
+            assert band.tobytes() == ref[8:17].tobytes()
+            res.set_output_format(_ffi.RM_FORMAT_RGBA32F)
+        from ray_marching_amd import shard
+        W, H = 64, 48
+        cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=(0.01, 100.0, 96), kernel=kernel)
+        res.set_output_format(fmt)
+        full = np.zeros((H, W, 4), np.uint8)
+        for rank in range(2):
+            shard.scatter_strips(full, res.draw_strips(W, H, 16, rank, 2), H, rank, 2, 16)
+        assert full.tobytes() == ref_of(oracle, scenes.g32(), W, H, (0.01, 100.0, 96), bgra).tobytes()
+        frames = []
+        for ev in ([(1, 35.0, -25.0)], [(1, -60.0, 30.0)]):
+            uu, *_ = oracle.orbit_uniforms((float(W), float(H)), events=ev)
+            frames.append(uu)
+        batch = res.draw_batch([_ffi.Uniforms.from_buffer_copy(bytes(f)) for f in frames], W, H)
+        cc, w = oracle.serialize(*scenes.g32())
+        for i, f in enumerate(frames):
+            want = oracle.quantize_unorm8(oracle.render(f, (0.01, 100.0, 96), cc, w, W, H, threads=4), bgra=bgra)
+            assert batch[i].tobytes() == want.tobytes()
+        # the older kernels do not have an output stage
+        res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_MULTI1_LDS)
+        with pytest.raises(_ffi.RmError) as e:
+            res.draw(W, H)
+        assert e.value.status == _ffi.RM_ERR_ARG
+    finally:
+        res.set_output_format(_ffi.RM_FORMAT_RGBA32F)
+        res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
+
+
+def ref_of(oracle, scene, W, H, lim, bgra):
+    cc, w, u = oracle_case(oracle, scene, W, H, None)
+    return oracle.quantize_unorm8(oracle.render(u, lim, cc, w, W, H, threads=4), bgra=bgra)

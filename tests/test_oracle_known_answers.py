@@ -204,3 +204,15 @@ def test_render_analytic_sphere_mask(oracle):
     outer = disc < -0.08
     assert (~hit[outer]).all()
     assert np.array_equal(img[..., 3], np.ones((H, W), dtype=F))
+
+
+def test_unorm8_quantisation_known_answers(oracle):
+    """Output stage (extension): clamp, * 255, round to nearest EVEN; NaN -> 0; alpha 1.0 -> 255; channel order."""
+    import numpy as np
+    px = np.array([[0.0, 1.0, 0.5, 1.0],                      # 0.5 * 255 = 127.5 -> 128 (even)
+                   [2.5 / 255.0, 3.5 / 255.0, -0.25, 1.0],     # ties: 2.5 -> 2, 3.5 -> 4; negative -> 0
+                   [np.nan, np.inf, 1.5, 1.0],                 # NaN -> 0, inf and 1.5 -> 255
+                   [0.08944272, 0.11832160, 0.04472136, 1.0]], dtype=np.float32)   # the hand-derived hit colour of 8(c)
+    q = oracle.quantize_unorm8(px)
+    assert q.tolist() == [[0, 255, 128, 255], [2, 4, 0, 255], [0, 255, 255, 255], [23, 30, 11, 255]]
+    assert oracle.quantize_unorm8(px, bgra=True)[:, [2, 1, 0, 3]].tolist() == q.tolist()

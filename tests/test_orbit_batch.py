@@ -1,0 +1,92 @@
+"""Offline orbit batch (ray-marching_amd/orbit_batch.py): the host-side logic -- frame sharding, resume by frame
+index, PPM files -- without a GPU, and (marked gpu) the whole pipeline against the oracle."""
+import argparse
+import math
+import os
+
+import numpy as np
+import pytest
+
+import scenes
+from ray_marching_amd import orbit_batch, shard
+
+
+def test_ppm_files_and_resume_logic(tmp_path):
+    W, H, N = 7, 5, 10
+    out = str(tmp_path)
+    rng = np.random.default_rng(3)
+    # every frame of a 3-rank world is assigned to exactly one rank
+    owners = sorted(f for r in range(3) for f in shard.frames_of_rank(N, r, 3))
+    assert owners == list(range(N))
+    assert orbit_batch.frames_todo(out, N, 1, 3, W, H, "ppm") == [1, 4, 7]
+    img = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    p = orbit_batch.write_frame(out, 4, img, "ppm")
+    data = open(p, "rb").read()
+    assert data.startswith(b"P6\n7 5\n255\n") and len(data) == orbit_batch.expected_size(W, H, "ppm")
+    assert data[len(orbit_batch.ppm_header(W, H)):] == img[..., :3].tobytes()        # alpha dropped, rows top first
+    assert not os.path.exists(p + ".part")
+    assert orbit_batch.frames_todo(out, N, 1, 3, W, H, "ppm") == [1, 7]                # frame 4 is done
+    with open(orbit_batch.frame_path(out, 7, "ppm"), "wb") as fh:                      # a truncated file is NOT done
+        fh.write(data[:20])
+    assert orbit_batch.frames_todo(out, N, 1, 3, W, H, "ppm") == [1, 7]
+    assert orbit_batch.frames_todo(out, N, 1, 3, W + 1, H, "ppm") == [1, 4, 7]         # other size: nothing matches
+    f32 = rng.standard_normal((H, W, 4)).astype(np.float32)
+    q = orbit_batch.write_frame(out, 2, f32, "f32")
+    assert np.array_equal(np.fromfile(q, dtype=np.float32).reshape(H, W, 4), f32)
+    assert math.isclose(orbit_batch.orbit_yaw(256, 1024), math.pi / 2)
+
+
+def _args(out_dir, **kw):
+    d = dict(out_dir=str(out_dir), frames=6, width=64, height=40, scene="g8", max_iter=64, format="ppm", slots=3, writers=2)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["ppm", "f32"])
+def test_orbit_batch_matches_the_oracle_and_resumes(tmp_path, oracle, fmt):
+    a = _args(tmp_path, format=fmt)
+    s = orbit_batch.render_batch(a, rank=0, world=1, device=0)
+    assert s["frames_rendered"] == 6 and s["frames_skipped"] == 0
+    cc, w = oracle.serialize(*scenes.g8())
+    lim = (0.01, 100.0, a.max_iter)
+
+    def expect(f):
+        L = oracle.lib()
+        import ctypes as C
+        orb = type(oracle.orbit_uniforms((1.0, 1.0))[3])()
+        t = np.zeros(3, np.float32)
+        L.rmo_orbit_new(C.byref(orb), t.ctypes.data_as(C.POINTER(C.c_float)), 5.0)
+        orb.yaw, orb.pitch, orb.radius = orbit_batch.orbit_yaw(f, a.frames), -0.25, 5.0
+        pos, q = np.zeros(3, np.float32), np.zeros(4, np.float32)
+        L.rmo_orbit_camera(C.byref(orb), pos.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(C.POINTER(C.c_float)))
+        u = type(oracle.orbit_uniforms((1.0, 1.0))[0])()
+        assert L.rmo_prepare_uniforms(float(a.width), float(a.height), pos.ctypes.data_as(C.POINTER(C.c_float)),
+                                      q.ctypes.data_as(C.POINTER(C.c_float)), C.byref(u)) == 0
+        return oracle.render(u, lim, cc, w, a.width, a.height, threads=4)
+
+    for f in range(a.frames):
+        data = open(orbit_batch.frame_path(a.out_dir, f, fmt), "rb").read()
+        ref = expect(f)
+        if fmt == "ppm":
+            body = data[len(orbit_batch.ppm_header(a.width, a.height)):]
+            assert body == oracle.quantize_unorm8(ref)[..., :3].tobytes(), f
+        else:
+            assert data == ref.tobytes(), f
+    # resume: remove one frame, truncate another -> exactly those two are rendered again
+    os.remove(orbit_batch.frame_path(a.out_dir, 2, fmt))
+    with open(orbit_batch.frame_path(a.out_dir, 5, fmt), "r+b") as fh:
+        fh.truncate(100)
+    before = open(orbit_batch.frame_path(a.out_dir, 0, fmt), "rb").read()
+    s2 = orbit_batch.render_batch(a, rank=0, world=1, device=0)
+    assert s2["frames_rendered"] == 2 and s2["frames_skipped"] == 4
+    assert open(orbit_batch.frame_path(a.out_dir, 0, fmt), "rb").read() == before
+    assert orbit_batch.frames_todo(a.out_dir, a.frames, 0, 1, a.width, a.height, fmt) == []
+    # two ranks: disjoint halves
+    b = _args(tmp_path / "two", format=fmt)
+    s0 = orbit_batch.render_batch(b, rank=0, world=2, device=0)
+    s1 = orbit_batch.render_batch(b, rank=1, world=2, device=0)
+    assert s0["frames_rendered"] == 3 and s1["frames_rendered"] == 3
+    for f in range(b.frames):
+        assert open(orbit_batch.frame_path(b.out_dir, f, fmt), "rb").read() == \
+            open(orbit_batch.frame_path(a.out_dir, f, fmt), "rb").read()
