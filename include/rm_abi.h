@@ -66,6 +66,9 @@ typedef struct rm_limits {
  *   reference:  Sphere 0 (c.xyz, r)   Box 1 (c.xyz, half-extents.xyz)   Union 100   Subtraction 101
  *   extensions (NOT implemented by the reference, semantics in DESIGN.md section 8; only the v5 kernels):
  *               Plane 2 (n.xyz, h)   Cylinder 10 (c.xyz, r, half_h)   Intersection 102   SmoothUnion 110 (k)
+ *               space transformations, the slots the reference reserves by comment (builder.rs:16-23), written
+ *               Push(params), <one child>, Pop:  TranslationPush 200 (t.xyz) / Pop 201   RotationPush 202 (unit
+ *               quaternion w,i,j,k) / Pop 203   ScalePush 204 (uniform s) / Pop 205
  * Any other opcode is rejected with RM_ERR_OPCODE. */
 
 /* binding numbers of the reference's bind group (renderer.rs:60-94, 149-166) */
@@ -87,7 +90,9 @@ enum rm_status {
     RM_ERR_RANGE = -8,           /* row band / image size out of range, or max_iter > 65536 */
     RM_ERR_DEVICE = -9,          /* a HIP call failed; see rm_last_error */
     RM_ERR_NO_DEVICE = -10,      /* no usable GPU */
-    RM_ERR_ARG = -11             /* invalid enum / option value */
+    RM_ERR_ARG = -11,            /* invalid enum / option value */
+    RM_ERR_TRANSFORM = -12       /* transform push / pop (extension opcodes 200-205) not nested properly, deeper than 8,
+                                    or not around exactly one value */
 };
 
 /* rm_set_option / rm_get_info keys */

@@ -34,9 +34,14 @@ rmh_node* rmh_plane(const float normal[3], float h);
 rmh_node* rmh_cylinder(const float center[3], float radius, float half_height);
 rmh_node* rmh_intersection(const rmh_node* lhs, const rmh_node* rhs);
 rmh_node* rmh_smooth_union(const rmh_node* lhs, const rmh_node* rhs, float k);
+/* space transformations: the node types csg/mod.rs:41-44 reserves by comment (opcodes 200-205, builder.rs:16-23);
+ * the child is deep-copied; quaternion = (w, i, j, k), unit length; factor > 0 */
+rmh_node* rmh_translation(const rmh_node* child, const float offset[3]);
+rmh_node* rmh_rotation(const rmh_node* child, const float quaternion_wijk[4]);
+rmh_node* rmh_scale(const rmh_node* child, float factor);
 rmh_node* rmh_node_clone(const rmh_node* n);
 void rmh_node_free(rmh_node* n);
-/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced; with extension nodes: g8x, g32s, ext_mix); NULL if unknown. */
+/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced; with extension nodes: g8x, g32s, ext_mix, xform_mix); NULL if unknown. */
 rmh_node* rmh_scene(const char* name);
 
 /* ---- CSGCommandBufferBuilder */

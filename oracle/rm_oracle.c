@@ -62,7 +62,8 @@ enum {
     RMO_ERR_UNDERFLOW = -3,  /* binary operator with < 2 values on the stack */
     RMO_ERR_OVERFLOW = -4,   /* value stack deeper than 32 (wgsl:173) */
     RMO_ERR_EMPTY_RESULT = -5,
-    RMO_ERR_OPCODE = -6      /* unknown opcode (only in strict mode) */
+    RMO_ERR_OPCODE = -6,     /* unknown opcode (only in strict mode) */
+    RMO_ERR_TRANSFORM = -12  /* transform push/pop not nested properly, deeper than 8, or not around exactly one value */
 };
 
 /* ---- opcode numbering (csg/builder.rs:1-24) ------------------------------------- */
@@ -79,6 +80,16 @@ enum {
 #define RMO_CMD_CYLINDER 10u      /* center vec3, radius, half_h:   capped cylinder along y         */
 #define RMO_CMD_INTERSECTION 102u /*                                max(a, b)                       */
 #define RMO_CMD_SMOOTH_UNION 110u /* k f32:                         polynomial smooth minimum       */
+/* Space transformations: the six slots the reference reserves by comment (builder.rs:16-23: "1 child, transforms
+ * space").  A node is  Push(params), <the child's commands>, Pop.  Push saves the evaluation position and replaces
+ * it; Pop restores it (ScalePop also multiplies the child's value by the scale).  Both count as commands. */
+#define RMO_CMD_TRANSLATION_PUSH 200u /* t vec3:             pos = pos - t                                  */
+#define RMO_CMD_TRANSLATION_POP 201u
+#define RMO_CMD_ROTATION_PUSH 202u    /* q = (w,i,j,k) unit:  pos = conj(q) pos q  (the CHILD is rotated by q) */
+#define RMO_CMD_ROTATION_POP 203u
+#define RMO_CMD_SCALE_PUSH 204u       /* s f32 (uniform):     pos = pos / s                                  */
+#define RMO_CMD_SCALE_POP 205u        /*                      value = value * s                              */
+#define RMO_MAX_XFORM_DEPTH 8u
 
 /* ---- scalar helpers --------------------------------------------------------------- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -136,11 +147,29 @@ typedef struct {
 RMO_API int rmo_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_words,
                                  int strict_opcodes, uint32_t* out_max_depth) {
     uint32_t ptr = 0, depth = 0, max_depth = 0;
+    uint32_t xop[RMO_MAX_XFORM_DEPTH], xdepth[RMO_MAX_XFORM_DEPTH], xsize = 0; /* open transform scopes */
     if (cmd_count && !words) return RMO_ERR_NULL;
     for (uint32_t i = 0; i < cmd_count; i++) {
         if (ptr >= n_words) return RMO_ERR_TRUNCATED;
         uint32_t op = words[ptr++];
         switch (op) {
+        case RMO_CMD_TRANSLATION_PUSH:
+        case RMO_CMD_ROTATION_PUSH:
+        case RMO_CMD_SCALE_PUSH: {
+            uint32_t np = op == RMO_CMD_TRANSLATION_PUSH ? 3u : op == RMO_CMD_ROTATION_PUSH ? 4u : 1u;
+            if (ptr + np > n_words) return RMO_ERR_TRUNCATED;
+            ptr += np;
+            if (xsize == RMO_MAX_XFORM_DEPTH) return RMO_ERR_TRANSFORM;
+            xop[xsize] = op;
+            xdepth[xsize++] = depth;
+        } continue;
+        case RMO_CMD_TRANSLATION_POP:
+        case RMO_CMD_ROTATION_POP:
+        case RMO_CMD_SCALE_POP:
+            /* closes the innermost scope, which must be of its kind and have produced exactly one value */
+            if (xsize == 0 || xop[xsize - 1] + 1u != op || depth != xdepth[xsize - 1] + 1u) return RMO_ERR_TRANSFORM;
+            xsize--;
+            continue;
         case RMO_CMD_SPHERE:
             if (ptr + 4 > n_words) return RMO_ERR_TRUNCATED;
             ptr += 4; depth++; break;
@@ -170,9 +199,20 @@ RMO_API int rmo_validate_program(uint32_t cmd_count, const uint32_t* words, uint
         if (depth > 32) return RMO_ERR_OVERFLOW;
         if (depth > max_depth) max_depth = depth;
     }
+    if (xsize != 0) return RMO_ERR_TRANSFORM;
     if (cmd_count && depth < 1) return RMO_ERR_EMPTY_RESULT;
     if (out_max_depth) *out_max_depth = max_depth;
     return RMO_OK;
+}
+
+/* Rotation of p by conj(q), q = (w, a) a unit quaternion: p' = p + w t + (-a) x t with t = 2 ((-a) x p), every
+ * product and difference a separate binary32 operation in the order written (the kernels do the same). */
+static v3 rotate_conj(float w, v3 a, v3 p) {
+    v3 c = { p.y * a.z - p.z * a.y, p.z * a.x - p.x * a.z, p.x * a.y - p.y * a.x }; /* p x a = (-a) x p */
+    v3 t = { 2.0f * c.x, 2.0f * c.y, 2.0f * c.z };
+    v3 u = { t.y * a.z - t.z * a.y, t.z * a.x - t.x * a.z, t.x * a.y - t.y * a.x }; /* t x a = (-a) x t */
+    v3 r = { (p.x + w * t.x) + u.x, (p.y + w * t.y) + u.y, (p.z + w * t.z) + u.z };
+    return r;
 }
 
 /* map_scene (wgsl:187-203) with eval_cmd* (wgsl:205-252), stream reader (wgsl:152-170)
@@ -181,11 +221,43 @@ static float map_scene(const rmo_scene* sc, v3 pos) {
     if (sc->cmd_count == 0u) return sc->limits.max_dist; /* wgsl:189-191 */
     float stack[32];
     uint32_t size = 0, ptr = 0; /* wgsl:194-195 */
+    v3 pstack[RMO_MAX_XFORM_DEPTH];    /* extension: positions saved by transform pushes */
+    float sstack[RMO_MAX_XFORM_DEPTH]; /*            and the scale of ScalePush */
+    uint32_t xsize = 0;
     const uint32_t* w = sc->words;
     for (uint32_t idx = 0; idx < sc->cmd_count; idx++) {
         uint32_t cmd = w[ptr++]; /* wgsl:198 */
         float val;
         switch (cmd) {
+        case RMO_CMD_TRANSLATION_PUSH: { /* extension */
+            v3 t = { u2f(w[ptr]), u2f(w[ptr + 1]), u2f(w[ptr + 2]) };
+            ptr += 3;
+            pstack[xsize++] = pos;
+            pos.x = pos.x - t.x; pos.y = pos.y - t.y; pos.z = pos.z - t.z;
+        } continue;
+        case RMO_CMD_ROTATION_PUSH: { /* extension */
+            float qw = u2f(w[ptr]);
+            v3 a = { u2f(w[ptr + 1]), u2f(w[ptr + 2]), u2f(w[ptr + 3]) };
+            ptr += 4;
+            pstack[xsize++] = pos;
+            pos = rotate_conj(qw, a, pos);
+        } continue;
+        case RMO_CMD_SCALE_PUSH: { /* extension */
+            float sfac = u2f(w[ptr]);
+            ptr += 1;
+            pstack[xsize] = pos;
+            sstack[xsize++] = sfac;
+            pos.x = pos.x / sfac; pos.y = pos.y / sfac; pos.z = pos.z / sfac;
+        } continue;
+        case RMO_CMD_TRANSLATION_POP:
+        case RMO_CMD_ROTATION_POP:
+            pos = pstack[--xsize];
+            continue;
+        case RMO_CMD_SCALE_POP:
+            --xsize;
+            pos = pstack[xsize];
+            stack[size - 1] = stack[size - 1] * sstack[xsize];
+            continue;
         case RMO_CMD_SPHERE: { /* wgsl:229-233 */
             v3 c = { u2f(w[ptr]), u2f(w[ptr + 1]), u2f(w[ptr + 2]) };
             float r = u2f(w[ptr + 3]);
@@ -512,6 +584,15 @@ RMO_API void rmo_build_commands(const rmo_node* nodes, int32_t root, rmo_builder
         rmo_builder_push_param_vec3(b, n->p);
         rmo_builder_push_param_float(b, n->p[3]);
         rmo_builder_push_param_float(b, n->p[4]);
+        break;
+    case RMO_CMD_TRANSLATION_PUSH: /* extension: push(params), the child (lhs), pop */
+    case RMO_CMD_ROTATION_PUSH:
+    case RMO_CMD_SCALE_PUSH:
+        rmo_builder_push_command(b, n->kind);
+        for (uint32_t k = 0; k < (n->kind == RMO_CMD_TRANSLATION_PUSH ? 3u : n->kind == RMO_CMD_ROTATION_PUSH ? 4u : 1u); k++)
+            rmo_builder_push_param_float(b, n->p[k]);
+        rmo_build_commands(nodes, n->lhs, b);
+        rmo_builder_push_command(b, n->kind + 1u);
         break;
     case RMO_CMD_SMOOTH_UNION: /* extension: lhs, rhs, operator, k */
         rmo_build_commands(nodes, n->lhs, b);

@@ -14,6 +14,7 @@ import numpy as np
 
 F = np.float32
 CMD_SPHERE, CMD_BOX, CMD_UNION, CMD_SUBTRACTION = 0, 1, 100, 101
+CMD_TRANSLATION_PUSH, CMD_TRANSLATION_POP, CMD_ROTATION_PUSH, CMD_ROTATION_POP, CMD_SCALE_PUSH, CMD_SCALE_POP = range(200, 206)
 CMD_PLANE, CMD_CYLINDER, CMD_INTERSECTION, CMD_SMOOTH_UNION = 2, 10, 102, 110   # extensions (not in the reference)
 
 
@@ -67,9 +68,34 @@ def map_scene(cmd_count, words, max_dist, px, py, pz):
         return np.full(px.shape, F(max_dist), dtype=F)
     words = decode_words(words)
     stack = []
+    saved = []   # extension: (position, scale) saved by the transform pushes (opcodes 200-205)
     ptr = 0
     for _ in range(cmd_count):
         op = int(words[ptr]); ptr += 1
+        if op == CMD_TRANSLATION_PUSH:
+            tx, ty, tz = (_wf(words, ptr + k) for k in range(3)); ptr += 3
+            saved.append((px, py, pz, None))
+            px, py, pz = px - tx, py - ty, pz - tz
+            continue
+        if op == CMD_ROTATION_PUSH:
+            qw, ax, ay, az = (_wf(words, ptr + k) for k in range(4)); ptr += 4
+            saved.append((px, py, pz, None))
+            cx, cy, cz = py * az - pz * ay, pz * ax - px * az, px * ay - py * ax
+            tx, ty, tz = F(2) * cx, F(2) * cy, F(2) * cz
+            ux, uy, uz = ty * az - tz * ay, tz * ax - tx * az, tx * ay - ty * ax
+            px, py, pz = (px + qw * tx) + ux, (py + qw * ty) + uy, (pz + qw * tz) + uz
+            continue
+        if op == CMD_SCALE_PUSH:
+            sf = _wf(words, ptr); ptr += 1
+            saved.append((px, py, pz, sf))
+            with np.errstate(divide="ignore", invalid="ignore"):
+                px, py, pz = px / sf, py / sf, pz / sf
+            continue
+        if op in (CMD_TRANSLATION_POP, CMD_ROTATION_POP, CMD_SCALE_POP):
+            px, py, pz, sf = saved.pop()
+            if op == CMD_SCALE_POP:
+                stack[-1] = (stack[-1] * sf).astype(F)
+            continue
         if op == CMD_SPHERE:
             cx, cy, cz, r = (_wf(words, ptr + k) for k in range(4)); ptr += 4
             dx, dy, dz = px - cx, py - cy, pz - cz

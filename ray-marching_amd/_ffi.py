@@ -28,7 +28,7 @@ class Limits(C.Structure):
 # status codes (include/rm_abi.h enum rm_status)
 RM_OK, RM_ERR_NULL, RM_ERR_TRUNCATED, RM_ERR_STACK_UNDERFLOW, RM_ERR_STACK_OVERFLOW = 0, -1, -2, -3, -4
 RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVICE = -5, -6, -7, -8, -9
-RM_ERR_NO_DEVICE, RM_ERR_ARG = -10, -11
+RM_ERR_NO_DEVICE, RM_ERR_ARG, RM_ERR_TRANSFORM = -10, -11, -12
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
 RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
 RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE, RM_OPT_PRUNE = 5, 6, 7, 8, 9
@@ -165,10 +165,14 @@ def host_lib():
         L.rmh_cylinder.argtypes = [f32p, C.c_float, C.c_float]
         L.rmh_intersection.argtypes = [vp, vp]
         L.rmh_smooth_union.argtypes = [vp, vp, C.c_float]
+        L.rmh_translation.argtypes = [vp, f32p]
+        L.rmh_rotation.argtypes = [vp, f32p]
+        L.rmh_scale.argtypes = [vp, C.c_float]
         L.rmh_node_clone.argtypes = [vp]
         L.rmh_scene.argtypes = [C.c_char_p]
         for n in ("rmh_sphere", "rmh_box", "rmh_union", "rmh_subtraction", "rmh_node_clone", "rmh_scene",
-                  "rmh_builder_new", "rmh_plane", "rmh_cylinder", "rmh_intersection", "rmh_smooth_union"):
+                  "rmh_builder_new", "rmh_plane", "rmh_cylinder", "rmh_intersection", "rmh_smooth_union",
+                  "rmh_translation", "rmh_rotation", "rmh_scale"):
             getattr(L, n).restype = vp
         L.rmh_node_free.argtypes = [vp]
         L.rmh_node_free.restype = None

@@ -20,6 +20,7 @@ class CSGCommandType(enum.IntEnum):  # builder.rs:3-24
     Cylinder = 10
     Intersection = 102
     SmoothUnion = 110
+    TranslationPush, TranslationPop, RotationPush, RotationPop, ScalePush, ScalePop = 200, 201, 202, 203, 204, 205
 
 
 def _f3(v):
@@ -113,6 +114,22 @@ def Intersection(lhs, rhs):
 
 def SmoothUnion(lhs, rhs, k=0.25):
     return CSGNode(_ffi.host_lib().rmh_smooth_union(lhs._h, rhs._h, float(k)))
+
+
+def Translation(child, offset=(0.0, 0.0, 0.0)):
+    """The child moved by `offset` (node type reserved by comment in csg/mod.rs:41; opcodes 200 / 201)."""
+    return CSGNode(_ffi.host_lib().rmh_translation(child._h, _f3(offset)))
+
+
+def Rotation(child, quaternion=(1.0, 0.0, 0.0, 0.0)):
+    """The child rotated by the unit quaternion (w, i, j, k) (csg/mod.rs:42; opcodes 202 / 203)."""
+    q = (C.c_float * 4)(*[float(x) for x in quaternion])
+    return CSGNode(_ffi.host_lib().rmh_rotation(child._h, q))
+
+
+def Scale(child, factor=1.0):
+    """The child scaled uniformly by `factor` > 0 (csg/mod.rs:43; opcodes 204 / 205)."""
+    return CSGNode(_ffi.host_lib().rmh_scale(child._h, float(factor)))
 
 
 def scene(name):

@@ -21,12 +21,18 @@ enum class CSGCommandType : uint32_t {  // builder.rs:3-24
     Box = 1,
     Union = 100,
     Subtraction = 101,
-    // 200.. TranslationPush/Pop, RotationPush/Pop, ScalePush/Pop: reserved by comment in the reference, not built.
     // ---- extensions: NOT implemented by the reference (DESIGN.md "Extension node types") ----
     Plane = 2,           // slot the reference reserves by comment (builder.rs:8)
     Cylinder = 10,       // BASELINE.json config 2
     Intersection = 102,  // slot the reference reserves by comment (builder.rs:14)
     SmoothUnion = 110,   // BASELINE.json config 3
+    // space transformations: the six slots the reference reserves by comment (builder.rs:16-23, "1 child, transforms space")
+    TranslationPush = 200,
+    TranslationPop = 201,
+    RotationPush = 202,
+    RotationPop = 203,
+    ScalePush = 204,
+    ScalePop = 205,
 };
 
 struct CSGCommandBufferBuilder {  // builder.rs:26-62
@@ -125,9 +131,26 @@ struct SmoothUnion {  // extension: polynomial smooth minimum with blend width k
     void build_commands(CSGCommandBufferBuilder& builder) const;
 };
 
+// Space transformations (extension; the node types csg/mod.rs:41-44 reserves by comment): Push(params), child, Pop.
+struct Translation {  // the child moved by `offset`
+    NodeBox child;
+    std::array<float, 3> offset{0, 0, 0};
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+struct Rotation {  // the child rotated by the unit quaternion (w, i, j, k)
+    NodeBox child;
+    std::array<float, 4> quaternion{1, 0, 0, 0};
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+struct Scale {  // the child scaled uniformly by `factor` (> 0)
+    NodeBox child;
+    float factor = 1.0f;
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+
 class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands) + the extension node types
   public:
-    using Variant = std::variant<Sphere, Box, Union, Subtraction, Plane, Cylinder, Intersection, SmoothUnion>;
+    using Variant = std::variant<Sphere, Box, Union, Subtraction, Plane, Cylinder, Intersection, SmoothUnion, Translation, Rotation, Scale>;
     CSGNode(Sphere s) : v_(std::move(s)) {}
     CSGNode(Box b) : v_(std::move(b)) {}
     CSGNode(Union u) : v_(std::move(u)) {}
@@ -136,6 +159,9 @@ class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands) + the ex
     CSGNode(Cylinder c) : v_(std::move(c)) {}
     CSGNode(Intersection i) : v_(std::move(i)) {}
     CSGNode(SmoothUnion s) : v_(std::move(s)) {}
+    CSGNode(Translation t) : v_(std::move(t)) {}
+    CSGNode(Rotation r) : v_(std::move(r)) {}
+    CSGNode(Scale s) : v_(std::move(s)) {}
     void build_commands(CSGCommandBufferBuilder& builder) const {
         std::visit([&](const auto& n) { n.build_commands(builder); }, v_);
     }
@@ -176,6 +202,25 @@ inline void SmoothUnion::build_commands(CSGCommandBufferBuilder& builder) const 
     rhs->build_commands(builder);
     builder.push_command(CSGCommandType::SmoothUnion).push_param_float(k);
 }
+inline void Translation::build_commands(CSGCommandBufferBuilder& builder) const {
+    builder.push_command(CSGCommandType::TranslationPush).push_param_vec3(offset);
+    child->build_commands(builder);
+    builder.push_command(CSGCommandType::TranslationPop);
+}
+inline void Rotation::build_commands(CSGCommandBufferBuilder& builder) const {
+    builder.push_command(CSGCommandType::RotationPush);
+    for (float q : quaternion) builder.push_param_float(q);
+    child->build_commands(builder);
+    builder.push_command(CSGCommandType::RotationPop);
+}
+inline void Scale::build_commands(CSGCommandBufferBuilder& builder) const {
+    builder.push_command(CSGCommandType::ScalePush).push_param_float(factor);
+    child->build_commands(builder);
+    builder.push_command(CSGCommandType::ScalePop);
+}
+inline CSGNode make_translation(CSGNode child, std::array<float, 3> offset) { return CSGNode(Translation{NodeBox(std::move(child)), offset}); }
+inline CSGNode make_rotation(CSGNode child, std::array<float, 4> q) { return CSGNode(Rotation{NodeBox(std::move(child)), q}); }
+inline CSGNode make_scale(CSGNode child, float factor) { return CSGNode(Scale{NodeBox(std::move(child)), factor}); }
 inline CSGNode make_intersection(CSGNode a, CSGNode b) {
     return CSGNode(Intersection{NodeBox(std::move(a)), NodeBox(std::move(b))});
 }

@@ -101,7 +101,20 @@ inline CSGNode ext_mix() {  // every extension node type in one tree
     return csg::make_union(std::move(c), CSGNode(csg::Cylinder{{-1.4f, -0.6f, -0.5f}, 0.25f, 0.5f}));
 }
 
+inline CSGNode xform_mix() {  // space transformations, nested, around primitives and around a sub-tree
+    const float h = 0.70710678f;  // cos(45 deg) = sin(45 deg): quarter turns about z and x
+    CSGNode a = csg::make_translation(csg::make_rotation(CSGNode(csg::Box{{0, 0, 0}, {0.9f, 0.35f, 0.5f}}), {h, 0, 0, h}), {-1.1f, 0.2f, 0.0f});
+    CSGNode b = csg::make_scale(csg::make_union(CSGNode(csg::Sphere{{0, 0, 0}, 1.0f}), CSGNode(csg::Box{{0.9f, 0, 0}, {0.5f, 0.3f, 0.3f}})), 0.6f);
+    CSGNode c = csg::make_translation(
+        csg::make_rotation(csg::make_scale(csg::make_subtraction(CSGNode(csg::Box{{0, 0, 0}, {1, 1, 1}}), CSGNode(csg::Sphere{{0.4f, 0.4f, 0.4f}, 0.9f})), 0.45f),
+                           {0.9238795f, 0.2209424f, 0.2209424f, 0.2209424f}),
+        {1.2f, -0.3f, 0.4f});
+    CSGNode d = csg::make_rotation(CSGNode(csg::Cylinder{{0.0f, -0.9f, -0.9f}, 0.3f, 0.7f}), {h, h, 0, 0});
+    return csg::make_union(csg::make_union(csg::make_union(std::move(a), std::move(b)), std::move(c)), std::move(d));
+}
+
 inline std::optional<CSGNode> by_name(const std::string& name) {
+    if (name == "xform_mix") return xform_mix();
     if (name == "g8x") return g8x();
     if (name == "g32s") return g32s();
     if (name == "ext_mix") return ext_mix();

@@ -52,6 +52,8 @@ struct rm_ctx {
     RmDecoded decoded;
     RmRecord* d_prog = nullptr;
     size_t d_prog_cap = 0;
+    float4* d_bounds = nullptr;  // world-space bounding spheres of a program with transforms (RmDecoded::bounds)
+    size_t d_bounds_cap = 0;
     // scratch for host-destination draws and batch uniforms
     float* d_out = nullptr;
     size_t d_out_bytes = 0;
@@ -136,6 +138,25 @@ int ensure_program(rm_ctx* c) {
         if (e != hipSuccess) {
             c->cmd_dirty = true;
             return fail(c, RM_ERR_DEVICE, "hipMemcpy(program) failed: %s", hipGetErrorString(e));
+        }
+    }
+    if (!d.bounds.empty()) {
+        const size_t n = d.bounds.size() / 4u;
+        if (n > c->d_bounds_cap) {
+            if (c->d_bounds) (void)hipFree(c->d_bounds);
+            c->d_bounds = nullptr;
+            c->d_bounds_cap = 0;
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->d_bounds), std::max<size_t>(64, 2 * n) * sizeof(float4));
+            if (e != hipSuccess) {
+                c->cmd_dirty = true;
+                return fail(c, RM_ERR_DEVICE, "hipMalloc(bounds) failed: %s", hipGetErrorString(e));
+            }
+            c->d_bounds_cap = std::max<size_t>(64, 2 * n);
+        }
+        hipError_t e = hipMemcpy(c->d_bounds, d.bounds.data(), d.bounds.size() * sizeof(float), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            c->cmd_dirty = true;
+            return fail(c, RM_ERR_DEVICE, "hipMemcpy(bounds) failed: %s", hipGetErrorString(e));
         }
     }
     c->decoded = std::move(d);
@@ -252,7 +273,7 @@ int launch_multi(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipS
 template <int WPT>
 int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
     RmLaunch L = L_in;
-    bool cull = c->cull && L.n_rec <= 256u;
+    bool cull = c->cull && L.n_rec <= 256u && !c->decoded.cull_veto;
     if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi_w
     L.n_cull = cull ? L.n_rec : 0u;
     L.flags = cull ? 1u : 0u;
@@ -343,7 +364,9 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.strip_rows = strips.rows; L.strip_first = strips.first; L.strip_stride = strips.stride;
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
-    L.spill_depth = c->decoded.spill_depth;
+    L.value_spill_depth = c->decoded.spill_depth;
+    L.spill_depth = c->decoded.spill_depth + 3u * c->decoded.xform_depth;  // saved positions follow the value stack
+    L.bounds = c->decoded.has_xforms ? c->d_bounds : nullptr;
     L.n_cull = 0;
     L.flags = 0;
     L.n_cone = c->decoded.n_sphere;
@@ -514,6 +537,7 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_cost) (void)hipFree(c->d_cost);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_bounds) (void)hipFree(c->d_bounds);
     for (auto& e : c->tev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -924,6 +948,7 @@ RM_EXPORT const char* rm_status_string(int status) {
     case RM_ERR_DEVICE: return "HIP runtime error";
     case RM_ERR_NO_DEVICE: return "no GPU available";
     case RM_ERR_ARG: return "invalid argument";
+    case RM_ERR_TRANSFORM: return "transform push/pop commands are not properly nested around one value";
     default: return "unknown status";
     }
 }

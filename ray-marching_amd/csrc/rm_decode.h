@@ -22,6 +22,19 @@ struct RmDecoded {
     // 1-Lipschitz leaf or a min/max operator; scene_scale = 1 + max over primitives of |centre|_1 + |size|_1
     bool prunable = true;
     float scene_scale = 1.0f;
+    // Space transformations (extension): deepest nesting, and -- because a transformed primitive's parameters no longer
+    // say where it is -- one world-space bounding sphere (x, y, z, radius) per bounded primitive for the miss tests.
+    // cull_veto: some transform is not a similarity (non-unit quaternion, scale not positive and finite): no culling.
+    uint32_t xform_depth = 0;
+    bool has_xforms = false, cull_veto = false;
+    std::vector<float> bounds;  // 4 floats per cone slot; empty unless has_xforms
+};
+
+// One open transform scope during decoding.
+struct RmXformScope {
+    uint32_t op;      // the push opcode
+    uint32_t depth;   // value-stack depth at the push
+    double p[4];      // its parameters
 };
 
 // Returns RM_OK or a negative rm_status.  `cap_words` is the number of u32 words that
@@ -33,12 +46,58 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
     // Every command is at least one word, so at most cap_words records can ever be produced.
     d.rec.reserve(cmd_count < cap_words ? cmd_count : cap_words);
     uint32_t ptr = 0, depth = 0, spilled = 0;
+    {   // does the program use transforms at all?  (decides where the miss tests take a primitive's position from)
+        uint32_t q = 0;
+        for (uint32_t i = 0; i < cmd_count && q < cap_words; i++) {
+            const uint32_t op = words[q++];
+            if (op >= RM_CMD_TRANSLATION_PUSH && op <= RM_CMD_SCALE_POP) { d.has_xforms = true; break; }
+            q += op == RM_CMD_SPHERE || op == RM_CMD_PLANE ? 4u : op == RM_CMD_BOX ? 6u : op == RM_CMD_CYLINDER ? 5u
+               : op == RM_CMD_SMOOTH_UNION ? 1u : 0u;
+        }
+    }
+    std::vector<RmXformScope> scopes;
     for (uint32_t i = 0; i < cmd_count; i++) {
         if (ptr >= cap_words) return RM_ERR_TRUNCATED;
         uint32_t op = words[ptr++];
         RmRecord r;
         std::memset(&r, 0, sizeof r);
         uint32_t kind = RM_KIND_POP, np = 0;
+        if (op == RM_CMD_TRANSLATION_PUSH || op == RM_CMD_ROTATION_PUSH || op == RM_CMD_SCALE_PUSH) {
+            const uint32_t n = op == RM_CMD_TRANSLATION_PUSH ? 3u : op == RM_CMD_ROTATION_PUSH ? 4u : 1u;
+            if (ptr + n > cap_words) return RM_ERR_TRUNCATED;
+            if (scopes.size() == RM_MAX_XFORM_DEPTH) return RM_ERR_TRANSFORM;
+            std::memcpy(r.p, words + ptr, n * 4);
+            ptr += n;
+            RmXformScope sc{op, depth, {r.p[0], r.p[1], r.p[2], r.p[3]}};
+            if (op == RM_CMD_ROTATION_PUSH) {
+                const double nn = sc.p[0] * sc.p[0] + sc.p[1] * sc.p[1] + sc.p[2] * sc.p[2] + sc.p[3] * sc.p[3];
+                if (!(std::fabs(nn - 1.0) < 1.0e-4)) d.cull_veto = true;  // not a rotation (also takes NaN)
+            } else if (op == RM_CMD_SCALE_PUSH) {
+                if (!(sc.p[0] > 0.0 && sc.p[0] < 1.0e30)) d.cull_veto = true;
+            } else if (!(std::fabs(sc.p[0]) + std::fabs(sc.p[1]) + std::fabs(sc.p[2]) < 1.0e30)) {
+                d.cull_veto = true;
+            }
+            const uint32_t level = (uint32_t)scopes.size();
+            std::memcpy(&r.p[6], &level, 4);
+            scopes.push_back(sc);
+            if (scopes.size() > d.xform_depth) d.xform_depth = (uint32_t)scopes.size();
+            r.op = RM_OP(RM_KIND_XFORM, op == RM_CMD_TRANSLATION_PUSH ? RM_XF_T_PUSH : op == RM_CMD_ROTATION_PUSH ? RM_XF_R_PUSH : RM_XF_S_PUSH, 0);
+            d.has_extensions = true;
+            d.prunable = false;
+            d.rec.push_back(r);
+            continue;
+        }
+        if (op == RM_CMD_TRANSLATION_POP || op == RM_CMD_ROTATION_POP || op == RM_CMD_SCALE_POP) {
+            // closes the innermost scope, which must be of its kind and have produced exactly one value
+            if (scopes.empty() || scopes.back().op + 1u != op || depth != scopes.back().depth + 1u) return RM_ERR_TRANSFORM;
+            const uint32_t level = (uint32_t)scopes.size() - 1u;
+            r.p[0] = (float)scopes.back().p[0];  // ScalePop multiplies the child's value by its push's scale
+            std::memcpy(&r.p[6], &level, 4);
+            scopes.pop_back();
+            r.op = RM_OP(RM_KIND_XFORM, op == RM_CMD_TRANSLATION_POP ? RM_XF_T_POP : op == RM_CMD_ROTATION_POP ? RM_XF_R_POP : RM_XF_S_POP, 0);
+            d.rec.push_back(r);
+            continue;
+        }
         switch (op) {
         case RM_CMD_SPHERE: kind = RM_KIND_SPHERE; np = 4; break;
         case RM_CMD_BOX: kind = RM_KIND_BOX; np = 6; break;
@@ -59,8 +118,39 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
                 // pruning threshold of a sphere, pre-multiplied (see spec_sphere_far): radius * 1.000005, rounded up
                 if (kind == RM_KIND_SPHERE) r.p[4] = std::nextafterf((float)((double)r.p[3] * 1.000005), INFINITY);
             }
-            // slot in the kernels' per-kind miss-test tables: cones for spheres, slabs for boxes and cylinders
-            const uint32_t slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : (kind == RM_KIND_PLANE ? 0u : d.n_box++);
+            // slot in the kernels' per-kind miss-test tables: cones for spheres, slabs for boxes and cylinders; in a
+            // program with transforms every bounded primitive is a cone around its world-space bounding sphere
+            uint32_t slot = 0u;
+            if (d.has_xforms && kind != RM_KIND_PLANE) {
+                slot = d.n_sphere++;
+                double c[3] = {r.p[0], r.p[1], r.p[2]};
+                double rho = kind == RM_KIND_SPHERE ? std::fmax((double)r.p[3], 0.0)
+                           : kind == RM_KIND_BOX ? std::sqrt(std::pow(std::fmax((double)r.p[3], 0.0), 2) + std::pow(std::fmax((double)r.p[4], 0.0), 2) +
+                                                             std::pow(std::fmax((double)r.p[5], 0.0), 2))
+                           : std::sqrt(std::pow(std::fmax((double)r.p[3], 0.0), 2) + std::pow(std::fmax((double)r.p[4], 0.0), 2));
+                for (size_t k = scopes.size(); k-- > 0;) {  // innermost scope first: local -> world
+                    const RmXformScope& sc = scopes[k];
+                    if (sc.op == RM_CMD_TRANSLATION_PUSH) {
+                        c[0] += sc.p[0]; c[1] += sc.p[1]; c[2] += sc.p[2];
+                    } else if (sc.op == RM_CMD_SCALE_PUSH) {
+                        c[0] *= sc.p[0]; c[1] *= sc.p[0]; c[2] *= sc.p[0];
+                        rho *= std::fabs(sc.p[0]);
+                    } else {  // x_world = q x conj(q)
+                        const double w = sc.p[0], a[3] = {sc.p[1], sc.p[2], sc.p[3]};
+                        const double cx[3] = {a[1] * c[2] - a[2] * c[1], a[2] * c[0] - a[0] * c[2], a[0] * c[1] - a[1] * c[0]};
+                        const double t[3] = {2.0 * cx[0], 2.0 * cx[1], 2.0 * cx[2]};
+                        const double u[3] = {a[1] * t[2] - a[2] * t[1], a[2] * t[0] - a[0] * t[2], a[0] * t[1] - a[1] * t[0]};
+                        for (int m = 0; m < 3; m++) c[m] = c[m] + w * t[m] + u[m];
+                        rho *= 1.0 + 1.0e-3;  // |q| within 5e-5 of 1 (else cull_veto): lengths change by < 1e-4
+                    }
+                }
+                const double mag = std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + rho;
+                d.bounds.push_back((float)c[0]); d.bounds.push_back((float)c[1]); d.bounds.push_back((float)c[2]);
+                d.bounds.push_back(std::nextafterf((float)(rho * (1.0 + 1.0e-5) + 1.0e-6 * mag), INFINITY));
+                if (!(mag < 1.0e30)) d.cull_veto = true;
+            } else {
+                slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : (kind == RM_KIND_PLANE ? 0u : d.n_box++);
+            }
             std::memcpy(&r.p[6], &slot, 4);
             // Fuse with a directly following parameter-less binary operator: its rhs is this leaf.
             uint32_t mode = RM_MODE_PUSH;
@@ -106,6 +196,7 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             return RM_ERR_OPCODE;
         }
     }
+    if (!scopes.empty()) return RM_ERR_TRANSFORM;
     if (cmd_count && depth < 1) return RM_ERR_EMPTY_RESULT;
     d.n_words = ptr;
     *out = std::move(d);

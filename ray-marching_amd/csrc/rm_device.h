@@ -27,8 +27,12 @@ struct RmRecord {
 };
 static_assert(sizeof(RmRecord) == 32, "record must be 32 bytes");
 
-enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2, RM_KIND_CYLINDER = 3, RM_KIND_PLANE = 4 };
+enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2, RM_KIND_CYLINDER = 3, RM_KIND_PLANE = 4,
+                  RM_KIND_XFORM = 5 };  // space transformation: mode = RM_XF_*, p[0..3] = parameters (ScalePop: the scale of
+                                        // its push), p[6] = level of the position stack
 enum : uint32_t { RM_MODE_PUSH = 0, RM_MODE_UNION = 1, RM_MODE_SUB = 2, RM_MODE_INTER = 3, RM_MODE_SMOOTH = 4 };
+enum : uint32_t { RM_XF_T_PUSH = 0, RM_XF_T_POP = 1, RM_XF_R_PUSH = 2, RM_XF_R_POP = 3, RM_XF_S_PUSH = 4, RM_XF_S_POP = 5 };
+enum : uint32_t { RM_MAX_XFORM_DEPTH = 8 };
 #define RM_OP(kind, mode, spill) ((uint32_t)(kind) | ((uint32_t)(mode) << 3) | ((uint32_t)(spill) << 6))
 #define RM_OP_KIND(op) ((op) & 7u)
 #define RM_OP_MODE(op) (((op) >> 3) & 7u)
@@ -40,11 +44,17 @@ enum : uint32_t { RM_CMD_SPHERE = 0, RM_CMD_BOX = 1, RM_CMD_UNION = 100, RM_CMD_
 // Intersection use the slots the reference reserves by comment (builder.rs:8,14); Cylinder and
 // SmoothUnion (BASELINE.json configs 2-3) stay clear of every reserved slot (2, 102, 200-205).
 enum : uint32_t { RM_CMD_PLANE = 2, RM_CMD_CYLINDER = 10, RM_CMD_INTERSECTION = 102, RM_CMD_SMOOTH_UNION = 110 };
+// Space transformations: the slots the reference reserves by comment (builder.rs:16-23).  Push(params), one child, Pop.
+enum : uint32_t { RM_CMD_TRANSLATION_PUSH = 200, RM_CMD_TRANSLATION_POP = 201, RM_CMD_ROTATION_PUSH = 202,
+                  RM_CMD_ROTATION_POP = 203, RM_CMD_SCALE_PUSH = 204, RM_CMD_SCALE_POP = 205 };
 
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
     uint32_t n_rec;            // == cmd_count of the reference program
-    uint32_t spill_depth;      // LDS value-stack slots per lane this program needs
+    uint32_t spill_depth;      // LDS slots per lane this program needs: value stack, then 3 per transform level
+    uint32_t value_spill_depth; // the value-stack part of spill_depth (saved positions start at this slot)
+    const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:
+                               // programs with transforms (their miss tests use these instead of the parameters)
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
     uint32_t flags;            // bit 0: miss-ray culling enabled
     uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program

@@ -78,6 +78,18 @@ RMH_EXPORT rmh_node* rmh_smooth_union(const rmh_node* lhs, const rmh_node* rhs, 
     if (!lhs || !rhs) return nullptr;
     return new (std::nothrow) rmh_node{csg::make_smooth_union(lhs->node, rhs->node, k)};
 }
+RMH_EXPORT rmh_node* rmh_translation(const rmh_node* child, const float offset[3]) {
+    if (!child || !offset) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_translation(child->node, a3(offset))};
+}
+RMH_EXPORT rmh_node* rmh_rotation(const rmh_node* child, const float quaternion_wijk[4]) {
+    if (!child || !quaternion_wijk) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_rotation(child->node, {quaternion_wijk[0], quaternion_wijk[1], quaternion_wijk[2], quaternion_wijk[3]})};
+}
+RMH_EXPORT rmh_node* rmh_scale(const rmh_node* child, float factor) {
+    if (!child) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_scale(child->node, factor)};
+}
 RMH_EXPORT rmh_node* rmh_node_clone(const rmh_node* n) { return n ? new (std::nothrow) rmh_node{n->node} : nullptr; }
 RMH_EXPORT void rmh_node_free(rmh_node* n) { delete n; }
 RMH_EXPORT rmh_node* rmh_scene(const char* name) {

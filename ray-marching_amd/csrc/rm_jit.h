@@ -99,8 +99,8 @@ inline std::string structure_key(const std::vector<RmRecord>& rec) {
     std::string k;
     k.reserve(rec.size() * 2);
     for (const RmRecord& r : rec) {
-        k.push_back("PSBCL???"[RM_OP_KIND(r.op)]);
-        k.push_back("pusix???"[RM_OP_MODE(r.op)]);
+        k.push_back("PSBCLX??"[RM_OP_KIND(r.op)]);
+        k.push_back("pusixy??"[RM_OP_MODE(r.op)]);
     }
     return k;
 }
@@ -125,10 +125,43 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
         s += "    const float inf = __uint_as_float(0x7F800000u);\n";
     }
     std::vector<int> stack;  // value numbers; back() is the accumulator
-    int nv = 0;
+    std::vector<int> pos;    // position numbers of the open transform scopes; back() is the current one (0 = qx, qy, qz)
+    int nv = 0, np = 0;
+    s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
+    pos.push_back(0);
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
         const unsigned off = (unsigned)i * 8u + 1u;  // first parameter of record i, in dwords
+        if (kind == RM_KIND_XFORM) {  // space transformation: a new position value (push) or back to the enclosing one (pop)
+            const int c = pos.back();
+            if ((mode & 1u) == 0u) {
+                const int n = ++np;
+                if (mode == RM_XF_T_PUSH)
+                    std::snprintf(line, sizeof line, "    const float x%d = x%d - lp[%u], y%d = y%d - lp[%u], z%d = z%d - lp[%u];\n",
+                                  n, c, off, n, c, off + 1u, n, c, off + 2u);
+                else if (mode == RM_XF_R_PUSH)
+                    std::snprintf(line, sizeof line, "    float x%d = x%d, y%d = y%d, z%d = z%d; xf_rotate_conj(lp[%u], lp[%u], lp[%u], lp[%u], x%d, y%d, z%d);\n",
+                                  n, c, n, c, n, c, off, off + 1u, off + 2u, off + 3u, n, n, n);
+                else
+                    std::snprintf(line, sizeof line, "    const float x%d = x%d / lp[%u], y%d = y%d / lp[%u], z%d = z%d / lp[%u];\n",
+                                  n, c, off, n, c, off, n, c, off);
+                s += line;
+                pos.push_back(n);
+            } else {
+                if (pos.size() < 2 || stack.empty()) return false;
+                pos.pop_back();
+                if (mode == RM_XF_S_POP) {
+                    const int a = stack.back(); stack.pop_back();
+                    const int w = nv++;
+                    std::snprintf(line, sizeof line, "    const float v%d = v%d * lp[%u];\n", w, a, off);
+                    s += line;
+                    stack.push_back(w);
+                }
+            }
+            continue;
+        }
+        char P[64];  // "xN, yN, zN": the position this record's leaf is evaluated at
+        std::snprintf(P, sizeof P, "x%d, y%d, z%d", pos.back(), pos.back(), pos.back());
         const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
         if (kind == RM_KIND_POP) {
             if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
@@ -158,10 +191,10 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
             s += line;
             char leaf[128];
             if (kind == RM_KIND_SPHERE) {
-                std::snprintf(line, sizeof line, "    { const float a = spec_sphere_a(lp + %u, qx, qy, qz);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", off, off);
+                std::snprintf(line, sizeof line, "    { const float a = spec_sphere_a(lp + %u, %s);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", off, P, off);
                 std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
             } else {
-                std::snprintf(line, sizeof line, "    { const SpecBox b = spec_box_a(lp + %u, qx, qy, qz);\n      if (spec_any_near(live, b.a > thr2k)) ", off);
+                std::snprintf(line, sizeof line, "    { const SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_any_near(live, b.a > thr2k)) ", off, P);
                 std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
             }
             s += line;
@@ -173,8 +206,8 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
                            : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
             if (!fn) return false;
             char leaf[128];
-            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, qx, qy, qz)", fn, off);
-            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, qx, qy, qz, tiny)", fn, off);
+            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, %s)", fn, off, P);
+            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, %s, tiny)", fn, off, P);
             if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d = %s;\n", w, leaf);
             else std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, %s);\n", w, op, a, leaf);
             s += line;

@@ -98,17 +98,46 @@ RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], S
     return fmin_(fmax_(qx, qy), 0.0f) + sqrt_sel<FAST, true>(mx * mx + my * my, tiny);
 }
 
+// Space transformations (extension; semantics: oracle/rm_oracle.c map_scene, opcodes 200-205).  Every product and
+// difference is one binary32 operation, in the oracle's order.
+RM_DEV void xf_rotate_conj(float w, float ax, float ay, float az, float& x, float& y, float& z) {
+    const float cx = y * az - z * ay, cy = z * ax - x * az, cz = x * ay - y * ax;  // p x a = (-a) x p
+    const float tx = 2.0f * cx, ty = 2.0f * cy, tz = 2.0f * cz;
+    const float ux = ty * az - tz * ay, uy = tz * ax - tx * az, uz = tx * ay - ty * ax;  // t x a
+    x = (x + w * tx) + ux;
+    y = (y + w * ty) + uy;
+    z = (z + w * tz) + uz;
+}
+
 // One decoded command applied to the R positions of a lane.
 // EXT = false compiles the reference's four node types only (the lean, measured path); EXT = true
 // adds the extension node types.  Which one runs is decided per program on the host.
 template <int R, bool FAST, bool EXT = false>
-RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R], const float (&qy)[R],
-                         const float (&qz)[R], float (&acc)[R], float* spill, uint32_t& sp, SqrtGuard& tiny) {
+RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float (&qy)[R], float (&qz)[R], float (&acc)[R],
+                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u) {
     // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
     op = __builtin_amdgcn_readfirstlane(op);
     const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
+    if constexpr (EXT) {
+        if (kind == RM_KIND_XFORM) {  // extension: the evaluation position changes; saved positions live in LDS
+            float* save = spill + (size_t)(xf_base + 3u * __float_as_uint(p[6])) * R * 64u;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                if ((mode & 1u) == 0u) {  // push
+                    save[(0 * R + k) * 64] = qx[k]; save[(1 * R + k) * 64] = qy[k]; save[(2 * R + k) * 64] = qz[k];
+                    if (mode == RM_XF_T_PUSH) { qx[k] = qx[k] - p[0]; qy[k] = qy[k] - p[1]; qz[k] = qz[k] - p[2]; }
+                    else if (mode == RM_XF_R_PUSH) xf_rotate_conj(p[0], p[1], p[2], p[3], qx[k], qy[k], qz[k]);
+                    else { qx[k] = qx[k] / p[0]; qy[k] = qy[k] / p[0]; qz[k] = qz[k] / p[0]; }
+                } else {  // pop
+                    qx[k] = save[(0 * R + k) * 64]; qy[k] = save[(1 * R + k) * 64]; qz[k] = save[(2 * R + k) * 64];
+                    if (mode == RM_XF_S_POP) acc[k] = acc[k] * p[0];
+                }
+            }
+            return;
+        }
+    }
     float a[R], b[R];
     if (kind == RM_KIND_POP) {
         --sp;
@@ -169,8 +198,12 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], const float (&qx)[R],
 // use (two buffers, loop unrolled by two) so that the fetch latency hides behind the VALU work
 // of the previous command.
 template <int R, bool FAST, class Prog, bool EXT = false>
-RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx)[R],
-                            const float (&qy)[R], const float (&qz)[R], float (&out)[R], SqrtGuard& tiny) {
+RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx_in)[R],
+                            const float (&qy_in)[R], const float (&qz_in)[R], float (&out)[R], SqrtGuard& tiny,
+                            uint32_t xf_base = 0u) {
+    float qx[R], qy[R], qz[R];  // transform commands (EXT) change the evaluation position
+#pragma unroll
+    for (int k = 0; k < R; k++) { qx[k] = qx_in[k]; qy[k] = qy_in[k]; qz[k] = qz_in[k]; }
     if (n_rec == 0u) {  // wgsl:189-191
 #pragma unroll
         for (int k = 0; k < R; k++) out[k] = max_dist;
@@ -185,7 +218,7 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
         uint32_t op0;
         float p0[7];
         prog.load(c, op0, p0);
-        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
     }
 #else
     uint32_t op0, op1;
@@ -193,10 +226,10 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     prog.load(0u, op0, p0);
     for (;;) {
         prog.load(c + 1u < n_rec ? c + 1u : c, op1, p1);
-        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
         if (++c == n_rec) break;
         prog.load(c + 1u < n_rec ? c + 1u : c, op0, p0);
-        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny);
+        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base);
         if (++c == n_rec) break;
     }
 #endif

@@ -157,18 +157,23 @@ RM_DEV float cull_margin(float cx, float cy, float cz, float rho, const V4& ro, 
 
 // Table entry (or entries) of one record; no-op for operators.  Called once per record per workgroup.
 RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, float slack, float4* cone, float4* slab,
-                          uint32_t* veto) {
-    const uint32_t kind = RM_OP_KIND(rec.op);
-    if (kind == RM_KIND_POP) return;
+                          uint32_t* veto, const float4* bounds = nullptr) {
+    uint32_t kind = RM_OP_KIND(rec.op);
+    if (kind == RM_KIND_POP || kind == RM_KIND_XFORM) return;
     if (kind == RM_KIND_PLANE) { *veto = 1u; return; }  // unbounded primitive: nothing can be culled
     const float inf = __uint_as_float(0x7F800000u);
     const uint32_t slot = __float_as_uint(rec.p[6]);
-    const float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2];
+    float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2], sphere_r = rec.p[3];
+    if (bounds) {  // program with transforms: the host computed a world-space bounding sphere for every bounded primitive
+        const float4 b = bounds[slot];
+        cx = b.x; cy = b.y; cz = b.z; sphere_r = b.w;
+        kind = RM_KIND_SPHERE;
+    }
     bool finite = __builtin_fabsf(cx) < inf && __builtin_fabsf(cy) < inf && __builtin_fabsf(cz) < inf &&
                   __builtin_fabsf(ro.x) < inf && __builtin_fabsf(ro.y) < inf && __builtin_fabsf(ro.z) < inf &&
                   __builtin_fabsf(min_dist) < inf;
     if (kind == RM_KIND_SPHERE) {
-        const float rho = fmax_(rec.p[3], 0.0f);
+        const float rho = fmax_(sphere_r, 0.0f);
         finite = finite && rho < inf;
         const float Rk = rho + cull_margin(cx, cy, cz, rho, ro, min_dist, slack);
         const float mx = cx - ro.x, my = cy - ro.y, mz = cz - ro.z;
@@ -283,7 +288,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();
     if (L.flags & 1u)
-        for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
+        for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto, L.bounds);
 
     Prog prog;
     if constexpr (PROG_IN_LDS) prog.base = lprog;
@@ -302,9 +307,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, is_live, tiny, again);
             }
         } else {
-            map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+            map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
             if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
-                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny);
+                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
         }
         return v[0];
     };
@@ -637,7 +642,7 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     __syncthreads();
     if (tables)
         for (uint32_t k = tid; k < L.n_rec; k += 64u * V5_PRE_TILES)
-            cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto);
+            cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto, L.bounds);
     __syncthreads();
     if (tables) {
         const float up = 1.0f + 1.0e-6f;
@@ -698,7 +703,7 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
 __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32_t* cost, uint32_t* order, uint32_t* counters,
                                                         uint32_t n_tiles, uint32_t balance) {
     __shared__ uint32_t hist[65], base[65];
-    __shared__ float f0_spill[32 * 64];
+    __shared__ float f0_spill[(32 + 3 * RM_MAX_XFORM_DEPTH) * 64];
     const uint32_t tid = threadIdx.x;
     // f0 = map_scene(ro): the first march step every ray of this frame shares (see rm_render_v5_body).  The
     // interpreter with the correctly rounded library sqrt gives the same bits as every kernel's evaluation.
@@ -711,7 +716,7 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32
         const float qx[1] = {ro.x}, qy[1] = {ro.y}, qz[1] = {ro.z};
         float v[1];
         SqrtGuard tiny;
-        map_scene_multi<1, false, ProgSmem, true>(prog, L.n_rec, f0_spill + (tid & 63u), L.max_dist, qx, qy, qz, v, tiny);
+        map_scene_multi<1, false, ProgSmem, true>(prog, L.n_rec, f0_spill + (tid & 63u), L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
         if (tid == 960u) counters[4u * blockIdx.x + 2u] = __float_as_uint(v[0]);
     }
     const uint32_t* c = cost + (size_t)blockIdx.x * n_tiles;

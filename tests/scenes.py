@@ -4,6 +4,7 @@ word for word.  A scene is (nodes, root) with nodes = [(kind, params, lhs, rhs),
 flat-table form oracle.cbind.serialize() takes."""
 SPHERE, BOX, UNION, SUBTRACTION = 0, 1, 100, 101
 PLANE, CYLINDER, INTERSECTION, SMOOTH_UNION = 2, 10, 102, 110    # extension node types (DESIGN.md)
+TRANSLATION, ROTATION, SCALE = 200, 202, 204                     # space transformations (push opcode; child = lhs)
 
 
 def _f32(x):
@@ -34,6 +35,18 @@ class _Tab:
 
     def cylinder(self, c, r, half_h):
         self.nodes.append((CYLINDER, [c[0], c[1], c[2], r, half_h], -1, -1))
+        return len(self.nodes) - 1
+
+    def translation(self, child, offset):
+        self.nodes.append((TRANSLATION, [offset[0], offset[1], offset[2]], child, -1))
+        return len(self.nodes) - 1
+
+    def rotation(self, child, q):
+        self.nodes.append((ROTATION, [q[0], q[1], q[2], q[3]], child, -1))
+        return len(self.nodes) - 1
+
+    def scale(self, child, s):
+        self.nodes.append((SCALE, [s], child, -1))
         return len(self.nodes) - 1
 
     def smooth_union(self, a, b, k):
@@ -154,8 +167,20 @@ def ext_mix():
     return t.nodes, t.op(UNION, c, t.cylinder((-1.4, -0.6, -0.5), 0.25, 0.5))
 
 
+def xform_mix():
+    """Space transformations, nested, around primitives and around a sub-tree."""
+    t = _Tab()
+    h = 0.70710678
+    a = t.translation(t.rotation(t.box((0, 0, 0), (0.9, 0.35, 0.5)), (h, 0, 0, h)), (-1.1, 0.2, 0.0))
+    b = t.scale(t.op(UNION, t.sphere((0, 0, 0), 1.0), t.box((0.9, 0, 0), (0.5, 0.3, 0.3))), 0.6)
+    c = t.translation(t.rotation(t.scale(t.op(SUBTRACTION, t.box((0, 0, 0), (1, 1, 1)), t.sphere((0.4, 0.4, 0.4), 0.9)), 0.45),
+                                 (0.9238795, 0.2209424, 0.2209424, 0.2209424)), (1.2, -0.3, 0.4))
+    d = t.rotation(t.cylinder((0.0, -0.9, -0.9), 0.3, 0.7), (h, h, 0, 0))
+    return t.nodes, t.op(UNION, t.op(UNION, t.op(UNION, a, b), c), d)
+
+
 SCENES = {"g1": g1, "g8": g8, "g32": g32, "g64": g64, "g32_balanced": g32_balanced}
-EXT_SCENES = {"g8x": g8x, "g32s": g32s, "ext_mix": ext_mix}
+EXT_SCENES = {"g8x": g8x, "g32s": g32s, "ext_mix": ext_mix, "xform_mix": xform_mix}
 
 # (events for OrbitCameraController::update) still camera of SURVEY 8(d): Orbit([35,-25])
 STILL_CAMERA_EVENTS = [(1, 35.0, -25.0)]

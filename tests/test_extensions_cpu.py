@@ -75,3 +75,65 @@ def test_truncated_extension_commands_are_rejected(oracle):
     for cc, words in [(1, [10, 0, 0, 0, 0]), (1, [2, 0, 0]), (3, [0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 110]), (1, [110, 0])]:
         rc, _ = renderer.validate_program(cc, words)
         assert rc < 0 and rc == oracle.validate(cc, words, strict=True)[0]
+
+
+# ---- space transformations (opcodes 200-205: the slots builder.rs:16-23 reserves by comment) ------------------
+def test_transform_wire_format_and_values(oracle):
+    import math
+    t = scenes._Tab()
+    cc, w = _words(t, t.translation(t.sphere((0, 0, 0), 1.0), (2.0, 0.0, 0.0)), oracle)
+    assert cc == 3 and [int(x) for x in w[[0, 4, 9]]] == [200, 0, 201] and len(w) == 10       # push t.xyz, child, pop
+    assert oracle.map_scene(cc, w, [5, 0, 0]) == 2.0
+    # box half-extents (1, .5, .25), quarter turn about z, scaled by 2, moved to (1, 2, 3):
+    # world half-extents (1, 2, .5) around (1, 2, 3)
+    t = scenes._Tab()
+    h = math.sqrt(0.5)
+    root = t.translation(t.scale(t.rotation(t.box((0, 0, 0), (1.0, 0.5, 0.25)), (h, 0, 0, h)), 2.0), (1.0, 2.0, 3.0))
+    cc, w = _words(t, root, oracle)
+    assert cc == 7 and [int(x) for x in w[[0, 4, 6]]] == [200, 204, 202] and [int(x) for x in w[-3:]] == [203, 205, 201]
+    for p, want in [((1, 2, 3), -0.5), ((1, 5, 3), 1.0), ((3, 2, 3), 1.0), ((1, 2, 4.5), 1.0), ((1, 2, 3.25), -0.25)]:
+        got = oracle.map_scene(cc, w, list(p))
+        assert abs(got - want) < 1e-6, (p, got, want)
+        npv = onp.map_scene(cc, w, 100.0, np.array([p[0]], F), np.array([p[1]], F), np.array([p[2]], F))[0]
+        assert F(got).tobytes() == F(npv).tobytes()
+    # the scale multiplies the child's value on the way out: a unit sphere scaled by 3, seen from distance 10
+    t = scenes._Tab()
+    cc, w = _words(t, t.scale(t.sphere((0, 0, 0), 1.0), 3.0), oracle)
+    assert oracle.map_scene(cc, w, [10, 0, 0]) == 7.0
+    # python constructors produce the same words
+    n = csg.Translation(csg.Scale(csg.Rotation(csg.Box((0, 0, 0), (1.0, 0.5, 0.25)), (h, 0, 0, h)), 2.0), (1.0, 2.0, 3.0))
+    t = scenes._Tab()
+    cc2, w2 = _words(t, t.translation(t.scale(t.rotation(t.box((0, 0, 0), (1.0, 0.5, 0.25)), (h, 0, 0, h)), 2.0), (1.0, 2.0, 3.0)), oracle)
+    cc1, w1 = csg.serialize(n)
+    assert cc1 == cc2 and np.array_equal(np.asarray(w1, np.uint32), np.asarray(w2, np.uint32))
+
+
+def test_transform_nesting_is_validated(oracle):
+    def both(cc, words):
+        w = np.array(words, dtype=np.uint32)
+        rc_o, _ = oracle.validate(cc, w)
+        rc_p, _ = renderer.validate_program(cc, w)
+        assert rc_o == rc_p, (rc_o, rc_p)
+        return rc_p
+
+    f = lambda x: int(np.float32(x).view(np.uint32))
+    S = [0, f(0), f(0), f(0), f(1)]                        # a sphere
+    T = [200, f(1), f(0), f(0)]
+    ERR = -12                                              # RM_ERR_TRANSFORM / RMO_ERR_TRANSFORM
+    assert both(3, T + S + [201]) == 0
+    assert both(2, T + S) == ERR                           # never closed
+    assert both(2, S + [201]) == ERR                       # pop without push
+    assert both(3, T + S + [203]) == ERR                   # closed by the wrong kind
+    assert both(2, T + [201]) == ERR                       # no child
+    assert both(4, T + S + S + [201]) == ERR               # two values inside one scope
+    assert both(5, S + T + S + [100, 201]) == ERR          # the operator reaches out of the scope
+    assert both(5, S + T + S + [201, 100]) == 0
+    deep = []
+    for _ in range(9):
+        deep += [204, f(1.0)]
+    assert both(9 + 1 + 9, deep + S + [205] * 9) == ERR    # nine levels: one too many
+    ok = []
+    for _ in range(8):
+        ok += [204, f(1.0)]
+    assert both(8 + 1 + 8, ok + S + [205] * 8) == 0
+    assert both(1, [202, f(1), f(0), f(0)]) == -2          # truncated parameters

@@ -599,3 +599,57 @@ def test_8bit_output_formats(res, oracle, fmt, bgra, kernel):
 def ref_of(oracle, scene, W, H, lim, bgra):
     cc, w, u = oracle_case(oracle, scene, W, H, None)
     return oracle.quantize_unorm8(oracle.render(u, lim, cc, w, W, H, threads=4), bgra=bgra)
+
+
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5", "v5_lds", "v5_spec"])
+def test_space_transformations_and_their_miss_tests(res, oracle, kernel):
+    """Translation / Rotation / Scale (opcodes 200-205): interpreter and specialised kernels against the oracle;
+    miss-ray culling of transformed primitives (world-space bounding spheres from the decoder) must never change a
+    pixel -- including programs whose transforms are not similarities, where culling has to step aside."""
+    import math
+    W, H = 80, 56
+    h = math.sqrt(0.5)
+
+    def tree(variant):
+        t = scenes._Tab()
+        if variant == "mix":
+            return scenes.xform_mix()
+        if variant == "deep":          # eight nested scopes around one box, next to an untransformed sphere
+            n = t.box((0.2, 0.0, 0.0), (0.5, 0.3, 0.2))
+            for k in range(8):
+                n = [t.translation(n, (0.1, -0.05, 0.02)), t.rotation(n, (math.cos(0.2), 0.0, math.sin(0.2), 0.0)),
+                     t.scale(n, 1.1)][k % 3]
+            return t.nodes, t.op(scenes.UNION, t.sphere((-1.2, 0, 0), 0.6), n)
+        if variant == "far":           # the transform moves a primitive into view from far away
+            return t.nodes, t.translation(t.sphere((100.0, 0, 0), 0.9), (-100.0, 0.2, 0.0))
+        if variant == "not_unit":      # |q| = 1.2: not a rotation (distances are distorted): culling must veto
+            return t.nodes, t.op(scenes.UNION, t.rotation(t.box((0, 0, 0), (0.7, 0.4, 0.3)), (1.2 * h, 0, 0, 1.2 * h)), t.sphere((1.5, 0, 0), 0.4))
+        if variant == "negative_scale":
+            return t.nodes, t.op(scenes.UNION, t.scale(t.sphere((0.5, 0.2, 0), 0.6), -1.5), t.box((-1.2, 0, 0), (0.3, 0.3, 0.3)))
+        if variant == "zero_scale":    # division by zero: NaN positions inside the scope
+            return t.nodes, t.op(scenes.UNION, t.scale(t.sphere((0, 0, 0), 0.6), 0.0), t.box((-1.2, 0, 0), (0.3, 0.3, 0.3)))
+        raise KeyError(variant)
+
+    res.resize_command_buffer(4096)
+    for variant in ("mix", "deep", "far", "not_unit", "negative_scale", "zero_scale"):
+        nodes, root = tree(variant)
+        cc, w = oracle.serialize(nodes, root)
+        for events in (scenes.STILL_CAMERA_EVENTS, [(1, 10.0, -150.0)], [(2, -95.0, 0.0)]):
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+            lim = (0.01, 100.0, 80)
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            res.set_option(_ffi.RM_OPT_CULL, 0)
+            off = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_CULL, 1)
+            on = res.draw(W, H)
+            assert off.tobytes() == ref.tobytes(), (variant, events, "cull off")
+            assert on.tobytes() == ref.tobytes(), (variant, events, "cull on")
+    res.resize_command_buffer(1024)
+    # a malformed nest is refused with the decoder's status
+    f = lambda x: int(np.float32(x).view(np.uint32))
+    with pytest.raises(_ffi.RmError) as e:
+        res.set_program(2, np.array([200, f(1), f(0), f(0), 0, f(0), f(0), f(0), f(1)], np.uint32))
+    assert e.value.status == _ffi.RM_ERR_TRANSFORM
+    cc, w = oracle.serialize(*scenes.g8())
+    res.set_program(cc, w)

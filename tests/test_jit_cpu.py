@@ -26,27 +26,28 @@ def test_generated_code_follows_the_postfix_program(oracle):
     cc, w = serialize(oracle, scenes.g8())     # ((S u B) - S) u B
     plain = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w))]
     assert plain == [
-        "const float v0 = spec_sphere<FAST>(lp + 1, qx, qy, qz, tiny);",
-        "const float v1 = vmin(v0, spec_box<FAST>(lp + 9, qx, qy, qz, tiny));",
-        "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 17, qx, qy, qz, tiny));",
-        "const float v3 = vmin(v2, spec_box<FAST>(lp + 25, qx, qy, qz, tiny));",
+        "const float x0 = qx, y0 = qy, z0 = qz;",
+        "const float v0 = spec_sphere<FAST>(lp + 1, x0, y0, z0, tiny);",
+        "const float v1 = vmin(v0, spec_box<FAST>(lp + 9, x0, y0, z0, tiny));",
+        "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 17, x0, y0, z0, tiny));",
+        "const float v3 = vmin(v2, spec_box<FAST>(lp + 25, x0, y0, z0, tiny));",
         "return v3;",
     ]
     body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True))]
-    assert body[:3] == ["const float thrk = thr * 1.000005f;", "const float thr2k = (thr * thr) * 1.00001f;",
-                        "const float inf = __uint_as_float(0x7F800000u);"]
-    assert body[3:] == [
+    assert body[:4] == ["const float thrk = thr * 1.000005f;", "const float thr2k = (thr * thr) * 1.00001f;",
+                        "const float inf = __uint_as_float(0x7F800000u);", "const float x0 = qx, y0 = qy, z0 = qz;"]
+    assert body[4:] == [
         "float v0 = inf;",
-        "{ const float a = spec_sphere_a(lp + 1, qx, qy, qz);",
+        "{ const float a = spec_sphere_a(lp + 1, x0, y0, z0);",
         "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); } }",
         "float v1 = v0;",
-        "{ const SpecBox b = spec_box_a(lp + 9, qx, qy, qz);",
+        "{ const SpecBox b = spec_box_a(lp + 9, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
-        "{ const float a = spec_sphere_a(lp + 17, qx, qy, qz);",
+        "{ const float a = spec_sphere_a(lp + 17, x0, y0, z0);",
         "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); } }",
         "float v3 = v2;",
-        "{ const SpecBox b = spec_box_a(lp + 25, qx, qy, qz);",
+        "{ const SpecBox b = spec_box_a(lp + 25, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
         "return v3;",
     ]
@@ -71,7 +72,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
     pending = None
     for line in body:
         line = line.strip()
-        if line.startswith("const float thr") or line.startswith("const float inf"):
+        if line.startswith("const float thr") or line.startswith("const float inf") or line.startswith("const float x0"):
             continue
         if line.startswith("return"):
             return env[line.rstrip(";").split()[1]]
