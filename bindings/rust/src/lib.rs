@@ -59,11 +59,24 @@ extern "C" {
     pub fn rm_sync(ctx: *mut rm_ctx) -> c_int;
     pub fn rm_set_option(ctx: *mut rm_ctx, key: c_int, value: i64) -> c_int;
     pub fn rm_get_info(ctx: *mut rm_ctx, key: c_int, out: *mut f64) -> c_int;
+    pub fn rm_jit_log(ctx: *mut rm_ctx, buf: *mut c_char, cap: usize) -> c_int;
     pub fn rm_last_error(ctx: *mut rm_ctx) -> *const c_char;
     pub fn rm_status_string(status: c_int) -> *const c_char;
 }
 
 #[derive(Debug)]
+// rm_set_option keys a host is likely to touch (include/rm_abi.h enum rm_option)
+pub const RM_OPT_SPECIALIZE: c_int = 8; // 0 interpreter kernel only, 1 (default) compile per scene structure in the background, 2 blocking
+pub const RM_OPT_OUTPUT_FORMAT: c_int = 10; // RM_FORMAT_*
+pub const RM_FORMAT_RGBA32F: i64 = 0;
+pub const RM_FORMAT_RGBA8_UNORM: i64 = 1;
+pub const RM_FORMAT_BGRA8_UNORM: i64 = 2; // what an egui/wgpu surface usually is (renderer.rs:113 `target_format`)
+
+// Opcodes of the node types the reference only names in comments (builder.rs:8,14,16-23) and that the device
+// path implements as extensions: a CSGCommandType that gains these variants serialises them unchanged.
+//   Plane = 2, Intersection = 102, TranslationPush = 200, TranslationPop, RotationPush, RotationPop, ScalePush, ScalePop
+//   (Cylinder = 10 and SmoothUnion = 110 are this repo's own numbers for BASELINE configs 2-3)
+
 pub struct RmError {
     pub status: i32,
     pub message: String,

@@ -34,6 +34,7 @@ CASES = [
     ("g8x_64", "g8x", 64, 64, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),
     ("g32s_64", "g32s", 64, 64, (0.01, 100.0, 256), scenes.STILL_CAMERA_EVENTS),
     ("ext_mix_64x48", "ext_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),
+    ("xform_mix_64x48", "xform_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),   # space transformations
 ]
 # larger renders pinned by checksum + counters only
 BIG = [
