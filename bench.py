@@ -42,6 +42,7 @@ def parse():
     p.add_argument("--prune", action="store_true", help="A/B: specialised kernel with far-primitive pruning (exact; measured slower)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
+    p.add_argument("--balance", type=int, default=-1, help="A/B: RM_OPT_BALANCE value (0 raster, 1 fullest tiles first, 2 silhouette tiles first)")
     p.add_argument("--camera", choices=["still", "orbit"], default="still")
     p.add_argument("--mode", choices=["frames", "tile"], default="frames",
                    help="frames: every rank renders whole frames (weak scaling, default); tile: ONE frame per step "
@@ -125,6 +126,8 @@ def main():
         res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, args.waves_per_tile)
     if args.no_cull:
         res.set_option(_ffi.RM_OPT_CULL, 0)
+    if args.balance >= 0:
+        res.set_option(_ffi.RM_OPT_BALANCE, args.balance)
     if args.no_balance:
         res.set_option(_ffi.RM_OPT_BALANCE, 0)
     res.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))

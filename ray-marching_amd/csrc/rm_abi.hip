@@ -64,7 +64,7 @@ struct rm_ctx {
     uint32_t refill_min = 8;
     uint32_t refill_min_v5 = 1;
     bool cull = true;
-    bool balance = true;
+    int balance = 1;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first
     int waves_per_tile = 4;
     bool wave_stats = false;
     unsigned long long* d_stats = nullptr;
@@ -293,7 +293,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames),
                        dim3(64u * rmk::V5_PRE_TILES), 16u + cull_bytes + (size_t)(L.n_cone + L.n_slab) * 8u, s, L, c->d_cost, n_tiles);
     hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, L, c->d_cost, c->d_order, c->d_counters,
-                       n_tiles, c->balance ? 1u : 0u);
+                       n_tiles, (uint32_t)c->balance);
     rmk::V5Work work{c->d_order, c->d_counters};
     // persistent grid: about as many workgroups as fit the chip (LDS, 32 waves per CU), never more than tiles
     uint32_t per_cu = (uint32_t)std::min<size_t>(32u / WPT, (160u * 1024u) / shmem);
@@ -736,7 +736,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_TIMING: c->timing = value != 0; c->tev_used = 0; return RM_OK;
     case RM_OPT_STRICT_CAP: return RM_OK;
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
-    case RM_OPT_BALANCE: c->balance = value != 0; return RM_OK;
+    case RM_OPT_BALANCE: c->balance = value < 0 ? 0 : value > 2 ? 2 : (int)value; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
     case RM_OPT_PRUNE: c->prune = value != 0; c->spec_gen = ~0ull; return RM_OK;
     case RM_OPT_OUTPUT_FORMAT:

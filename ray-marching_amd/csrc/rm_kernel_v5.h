@@ -455,6 +455,16 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         }
         n_iter++;
         n_live += (uint32_t)__popcll(__ballot(is_live));
+#ifdef RM_PRIO_LONG_RAYS
+        // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
+        // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
+        // issue priority: the chain runs at the lone-wave rate and the short rays fill in behind it.
+        if (!tapping) {
+            const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && it >= RM_PRIO_LONG_RAYS));
+            if (old_rays != 0u) __builtin_amdgcn_s_setprio(3);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const float sd = eval_scene(ex, ey, ez, thr, is_live);
 
         if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
@@ -736,7 +746,13 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32
     __syncthreads();
     if (tid == 0u) {
         uint32_t acc = 0u;
-        for (uint32_t b = 0; b < 65u; b++) { base[b] = acc; acc += hist[b]; }
+        if (balance == 2u) {  // partially covered tiles (silhouettes: that is where the rays that never converge are) first
+            for (uint32_t b = 1; b < 65u; b++) { base[b] = acc; acc += hist[b]; }
+            base[0] = acc;
+            acc += hist[0];
+        } else {
+            for (uint32_t b = 0; b < 65u; b++) { base[b] = acc; acc += hist[b]; }
+        }
         counters[4u * blockIdx.x] = acc;      // tiles on the work list
         counters[4u * blockIdx.x + 1u] = 0u;  // cursor
     }

@@ -16,6 +16,7 @@ p.add_argument("--height", type=int, default=1080)
 p.add_argument("--scene", default="g32")
 p.add_argument("--max-iter", type=int, default=256)
 p.add_argument("--no-balance", action="store_true")
+p.add_argument("--balance", type=int, default=-1)
 p.add_argument("--wpt", type=int, default=4)
 p.add_argument("--no-cull", action="store_true")
 p.add_argument("--specialize", type=int, default=2)
@@ -30,7 +31,7 @@ res.set_option(_ffi.RM_OPT_SPECIALIZE, a.specialize)
 res.set_option(_ffi.RM_OPT_PRUNE, 1 if a.prune else 0)
 if a.refill_min:
     res.set_option(_ffi.RM_OPT_REFILL_MIN, a.refill_min)
-res.set_option(_ffi.RM_OPT_BALANCE, 0 if a.no_balance else 1)
+res.set_option(_ffi.RM_OPT_BALANCE, a.balance if a.balance >= 0 else (0 if a.no_balance else 1))
 res.set_option(_ffi.RM_OPT_CULL, 0 if a.no_cull else 1)
 res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, a.wpt)
 res.set_limits(renderer.RayMarchLimits(0.01, 100.0, a.max_iter))
