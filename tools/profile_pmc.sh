@@ -6,9 +6,9 @@ set -e
 out=$1; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-B="bench.py --steps 10 --warmup 2 --no-cpu-baseline $*"
+B="bench.py --no-cpu-baseline --no-ab $*"   # the default bench command (200 timed steps after 20 warm-up)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/kt" -- python3 $B > "$out/kt.log" 2>&1
-B="bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
+B="bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-ab $*"   # counter passes: fewer dispatches
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY \
   --output-format csv -d "$out/pmc1" -- python3 $B > "$out/pmc1.log" 2>&1
 rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_INSTS_BRANCH GRBM_GUI_ACTIVE \
