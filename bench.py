@@ -52,7 +52,9 @@ def parse():
                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
     p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-ab", action="store_true", help="skip the interpreter-kernel A/B leg that follows the timed region")
+    p.add_argument("--no-ab", action="store_true", help="skip the serial and interpreter-kernel legs that follow the timed region")
+    p.add_argument("--frames-in-flight", type=int, default=2,
+                   help="frames drawn concurrently, each on its own context / stream / output buffer (1 = strictly serial)")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
     return p.parse_args()
 
@@ -115,27 +117,39 @@ def main():
     assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
 
     W, H = args.width, args.height
-    res = renderer.RayMarchingResources(local_rank)
-    res.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
-    res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
-    if args.prune:
-        res.set_option(_ffi.RM_OPT_PRUNE, 1)
-    if args.refill_min:
-        res.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
-    if args.waves_per_tile:
-        res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, args.waves_per_tile)
-    if args.no_cull:
-        res.set_option(_ffi.RM_OPT_CULL, 0)
-    if args.balance >= 0:
-        res.set_option(_ffi.RM_OPT_BALANCE, args.balance)
-    if args.no_balance:
-        res.set_option(_ffi.RM_OPT_BALANCE, 0)
-    res.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
+    from ray_marching_amd import shard
+    tile = args.mode == "tile"
+    # Frames in flight: frame f is drawn by context f % F on stream f % F into buffer f % F (a double-buffered renderer).
+    # A frame's draw ends with a tail in which its last tiles drain and most of the chip idles; the next frame's
+    # launches fill it.  F = 1 is the strictly serial loop.  (Tile mode gathers every frame: serial by nature.)
+    F = 1 if tile else max(1, args.frames_in_flight)
     node = csg.scene(args.scene)
     cc, words = csg.serialize(node)
-    if len(words) > 255:
-        res.resize_command_buffer(4 * (len(words) + 1 + 63) // 64 * 64)
-    res.set_program(cc, words)
+
+    def make_context():
+        r = renderer.RayMarchingResources(local_rank)
+        r.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
+        if args.prune:
+            r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        if args.refill_min:
+            r.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
+        if args.waves_per_tile:
+            r.set_option(_ffi.RM_OPT_WAVES_PER_TILE, args.waves_per_tile)
+        if args.no_cull:
+            r.set_option(_ffi.RM_OPT_CULL, 0)
+        if args.balance >= 0:
+            r.set_option(_ffi.RM_OPT_BALANCE, args.balance)
+        if args.no_balance:
+            r.set_option(_ffi.RM_OPT_BALANCE, 0)
+        r.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
+        if len(words) > 255:
+            r.resize_command_buffer(4 * (len(words) + 1 + 63) // 64 * 64)
+        r.set_program(cc, words)
+        return r
+
+    ctxs = [make_context() for _ in range(F)]
+    res = ctxs[0]
 
     still_events = [(1, 35.0, -25.0)]                      # Orbit([35,-25]): yaw 0.35, pitch -0.25
     ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
@@ -147,12 +161,12 @@ def main():
             ctl.set_angles(2.0 * 3.141592653589793 * f / 1024.0, -0.25, 5.0)
         return renderer.prepare_uniforms((float(W), float(H)), ctl.camera())
 
-    from ray_marching_amd import shard
-    tile = args.mode == "tile"
     my_rows = shard.strip_row_count(H, shard.DEFAULT_STRIP_ROWS, rank, world) if tile else H
-    out = torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda")
+    outs = [torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
+    out = outs[0]
     gloo = dist.new_group(backend="gloo") if (tile and args.gather and world > 1) else None
-    stream = torch.cuda.Stream()          # the kernel, the events and the syncs all use THIS stream
+    streams = [torch.cuda.Stream() for _ in range(F)]   # kernels, events and syncs of frame f all use stream f % F
+    stream = streams[0]
     torch.cuda.set_stream(stream)
     sptr = stream.cuda_stream
 
@@ -161,73 +175,81 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def draw():
+    def draw(i=0):
         if tile:
             res.draw_strips_device(W, H, shard.DEFAULT_STRIP_ROWS, rank, world, out.data_ptr(), stream=sptr)
             if args.gather:      # final host-side gather (D2H + gloo), never RCCL
                 stream.synchronize()
                 shard.gather_image(out[:my_rows].cpu().numpy(), W, H, rank, world, group=gloo)
         else:
-            res.draw_device(W, H, out.data_ptr(), stream=sptr)
+            ctxs[i].draw_device(W, H, outs[i].data_ptr(), stream=streams[i].cuda_stream)
 
     total = args.warmup + args.steps
     unis = [uniforms_for(s) for s in range(total)]
-    for s in range(args.warmup):
-        res.set_uniforms(unis[s])
-        draw()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    res.set_option(_ffi.RM_OPT_TIMING, 1)     # library-side HIP events around the march kernel itself
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        res.set_uniforms(unis[args.warmup + k])            # prepare(): uniform write
-        ev[k][0].record(stream)
-        draw()                                              # paint(): the kernel, on this stream
-        ev[k][1].record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    draw_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)    # all launches of a draw
-    kernel_ms = res.info(_ffi.RM_INFO_KERNEL_MS)                              # the dominant (march) kernel alone
+
+    def timed_run(n_ctx):
+        """W warm-up + K timed steps over the first n_ctx contexts.  Returns (seconds, mean per-draw ms from events,
+        mean march-kernel ms from the library's own events)."""
+        for s in range(args.warmup):
+            ctxs[s % n_ctx].set_uniforms(unis[s])
+            draw(s % n_ctx)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        for c in ctxs[:n_ctx]:
+            c.set_option(_ffi.RM_OPT_TIMING, 1)     # library-side HIP events around the march kernel itself
+        sync_all()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            i = k % n_ctx
+            ctxs[i].set_uniforms(unis[args.warmup + k])        # prepare(): uniform write
+            ev[k][0].record(streams[i])
+            draw(i)                                             # paint(): the kernels, on this frame's stream
+            ev[k][1].record(streams[i])
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        seconds = time.perf_counter() - t0
+        per_draw = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)    # all launches of a draw
+        kms = [c.info(_ffi.RM_INFO_KERNEL_MS) for c in ctxs[:n_ctx]]             # the dominant (march) kernel alone
+        for c in ctxs[:n_ctx]:
+            c.set_option(_ffi.RM_OPT_TIMING, 0)
+        return seconds, per_draw, sum(kms) / len(kms)
+
+    elapsed, draw_ms, kernel_ms = timed_run(F)
     specialized = bool(res.info(_ffi.RM_INFO_SPECIALIZED))                    # what the LAST timed launch ran
     jit_ms = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
-    res.set_option(_ffi.RM_OPT_TIMING, 0)
     if world > 1:
         t = torch.tensor([elapsed, kernel_ms, draw_ms], dtype=torch.float64,
                          device="cuda" if args.dist_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kernel_ms, draw_ms = float(t[0]), float(t[1]), float(t[2])
 
-    checksum = float(out[..., :3].double().sum().item())    # touches the result: nothing was skipped
+    checksum = float(outs[(args.steps - 1) % F][..., :3].double().sum().item())    # touches the result: nothing was skipped
 
-    # A/B leg (N = 1 only, after the timed region): the same frames through the interpreter kernel, i.e. the design
-    # north_star spells out (node array staged in LDS and INTERPRETED); reported beside the default path's number
-    ab = None
-    if world == 1 and specialized and not args.no_ab:
-        res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
-        for s in range(args.warmup):
-            draw()
-        res.set_option(_ffi.RM_OPT_TIMING, 1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for k in range(args.steps):
-            res.set_uniforms(unis[args.warmup + k])
-            draw()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        ab_checksum = float(out[..., :3].double().sum().item())
-        ab = {"kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine)",
-              "value": W * H * args.steps / dt / 1e6, "unit": "Mpixels/s", "kernel_ms": res.info(_ffi.RM_INFO_KERNEL_MS),
-              "same_image": ab_checksum == checksum}
-        res.set_option(_ffi.RM_OPT_TIMING, 0)
-        res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
+    # Legs after the timed region (N = 1 only), reported beside the headline number:
+    #   one_frame_in_flight     the strictly serial loop (what an interactive frame costs end to end)
+    #   ab_interpreter_kernel   the same, through the interpreter kernel, i.e. the design north_star spells out
+    #                           (node array staged in LDS and INTERPRETED)
+    serial = ab = None
+    if world == 1 and not tile and not args.no_ab:
+        if F > 1:
+            s_el, s_draw, s_k = timed_run(1)
+            serial = {"value": W * H * args.steps / s_el / 1e6, "unit": "Mpixels/s", "draw_ms": s_draw, "kernel_ms": s_k,
+                      "same_image": float(outs[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
+        if specialized:
+            res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
+            a_el, a_draw, a_k = timed_run(1)
+            ab = {"kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine), one frame in flight",
+                  "value": W * H * args.steps / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
+                  "same_image": float(outs[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
+            res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
     if rank == 0:
         pixels = W * H * args.steps * (1 if tile else world)
         value = pixels / elapsed / 1e6
         # whole-frame algorithmic bytes over the whole draw (pre-pass + sort + march kernel launches)
-        ach = BYTES_PER_PIXEL * W * (my_rows if tile else H) / (draw_ms * 1e-3) / 1e9
+        # launch duration of one frame's three kernels: with several frames in flight the event-bracketed draw also
+        # contains the time spent queued behind the other frame, so the serial leg's figure is the one that applies
+        draw_ms_launch = serial["draw_ms"] if serial is not None else draw_ms
+        ach = BYTES_PER_PIXEL * W * (my_rows if tile else H) / (draw_ms_launch * 1e-3) / 1e9
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tfile):
@@ -244,7 +266,7 @@ def main():
             "config": {"workload": "%dx%d, %s (%d commands / %d words), %d max steps, 16 rays/px, RGBA32F out"
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
                        "camera": args.camera, "kernel": args.kernel,
-                       "specialized_kernel": specialized, "jit_compile_ms": jit_ms,
+                       "specialized_kernel": specialized, "jit_compile_ms": jit_ms, "frames_in_flight": F,
                        "sharding": ("one frame tiled over ranks in interleaved 16-row strips%s, no collective"
                                     % (" + host gather" if args.gather else "")) if tile
                        else ("frames over ranks, no collective" if world > 1 else "single GPU")},
@@ -254,10 +276,17 @@ def main():
                                    + " = the dominant (march) kernel: kernel_ms; `achieved` divides the frame's "
                                    "bytes by draw_ms, the draw's three launches (pre-pass, sort, march)",
                          "kernel_ms": kernel_ms, "draw_ms": draw_ms,
+                         "draw_ms_one_frame_in_flight": draw_ms_launch,
+                         "frames_in_flight_note": ("%d frames in flight: a frame's event-bracketed draw_ms includes queueing behind "
+                                                   "the other frame and exceeds ms_per_step; `achieved` uses the launch duration "
+                                                   "of the same three kernels measured without overlap in this run "
+                                                   "(one_frame_in_flight), when that leg ran" % F) if F > 1 else None,
                          "note": "algorithmic bytes = 16 B/pixel (one RGBA32F store); the kernel is FP32-VALU "
                                  "bound by ~3 orders of magnitude, see `compute`"},
             "checksum_rgb": checksum,
         }
+        if serial is not None:
+            line["one_frame_in_flight"] = serial
         if ab is not None:
             line["ab_interpreter_kernel"] = ab
         if world == 1 and not args.no_cpu_baseline:
@@ -271,7 +300,8 @@ def main():
                                    "evals_per_s": evals / (kernel_ms * 1e-3),
                                    "note": "evaluations counted by the oracle on the CPU sample, scaled by pixel count"}
         print(json.dumps(line), flush=True)
-    res.close()
+    for c in ctxs:
+        c.close()
     if world > 1:
         dist.destroy_process_group()
 

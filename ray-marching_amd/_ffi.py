@@ -38,6 +38,7 @@ RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
 RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
 RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
 RM_JIT_PRUNE = 0x100
+RM_STREAM_OWN = (1 << 64) - 1   # (void*)-1: the context's own stream
 RM_OPT_OUTPUT_FORMAT = 10
 RM_FORMAT_RGBA32F, RM_FORMAT_RGBA8_UNORM, RM_FORMAT_BGRA8_UNORM = 0, 1, 2
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
@@ -100,6 +101,8 @@ def hip_lib():
         L.rm_draw_strips.restype = C.c_int
         L.rm_draw_batch.argtypes = [vp, C.POINTER(Uniforms), u32, u32, u32, vp, C.c_int, vp]
         L.rm_sync.argtypes = [vp]
+        L.rm_sync_context.argtypes = [vp]
+        L.rm_sync_context.restype = C.c_int
         L.rm_set_option.argtypes = [vp, C.c_int, i64]
         L.rm_get_info.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
         L.rm_measure_write_bandwidth.argtypes = [vp, u64, C.c_int, C.POINTER(C.c_double)]

@@ -476,6 +476,10 @@ int check_limits(rm_ctx* c) {
     return RM_OK;
 }
 
+hipStream_t user_stream(const rm_ctx* c, void* stream) {
+    return stream == RM_STREAM_OWN ? c->stream : static_cast<hipStream_t>(stream);
+}
+
 size_t pixel_bytes(const rm_ctx* c) { return c->out_format == RM_FORMAT_RGBA32F ? 16u : 4u; }
 
 int ensure_out(rm_ctx* c, size_t bytes) {
@@ -634,7 +638,7 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
     const size_t bytes = (size_t)rows * W * pixel_bytes(c);
-    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, static_cast<hipStream_t>(stream));
+    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, user_stream(c, stream));
     hipStream_t s = c->stream;
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
@@ -677,7 +681,7 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     StripSpec sp;
     sp.rows = strip_rows; sp.first = first; sp.stride = stride;
     const size_t bytes = (size_t)rows * W * pixel_bytes(c);
-    if (out_is_device) return launch(c, nullptr, 1, W, H, 0, rows, out_rgba, static_cast<hipStream_t>(stream), sp);
+    if (out_is_device) return launch(c, nullptr, 1, W, H, 0, rows, out_rgba, user_stream(c, stream), sp);
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
     rc = launch(c, nullptr, 1, W, H, 0, rows, c->d_out, c->stream, sp);
@@ -699,7 +703,7 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
-    hipStream_t s = out_is_device ? static_cast<hipStream_t>(stream) : c->stream;
+    hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
     if (n_frames > c->d_frames_cap) {
         if (c->d_frames) (void)hipFree(c->d_frames);
         c->d_frames = nullptr;
@@ -716,6 +720,13 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipMemcpyAsync(out_rgba, c->d_out, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(c, hipStreamSynchronize(s));
+    return RM_OK;
+}
+
+RM_EXPORT int rm_sync_context(rm_ctx* c) {
+    if (!c) return RM_ERR_NULL;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return RM_OK;
 }
 

@@ -128,6 +128,10 @@ class RayMarchingResources:
     def sync(self):
         self._check(self._L.rm_sync(self._h))
 
+    def sync_context(self):
+        """Wait for this context's own stream (draws issued with stream=_ffi.RM_STREAM_OWN)."""
+        self._check(self._L.rm_sync_context(self._h))
+
     # -- options / info ------------------------------------------------------------------------
     def set_option(self, key, value):
         self._check(self._L.rm_set_option(self._h, key, int(value)))

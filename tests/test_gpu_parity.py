@@ -653,3 +653,35 @@ def test_space_transformations_and_their_miss_tests(res, oracle, kernel):
     assert e.value.status == _ffi.RM_ERR_TRANSFORM
     cc, w = oracle.serialize(*scenes.g8())
     res.set_program(cc, w)
+
+
+def test_frames_in_flight_on_context_owned_streams(oracle):
+    """RM_STREAM_OWN / rm_sync_context: three contexts, frame f -> context f % 3, every frame on its context's own
+    stream into its own device buffer, one wait per context at the end -- the images are the serial ones."""
+    import torch
+    W, H, F = 96, 64, 3
+    cc, w = oracle.serialize(*scenes.g32())
+    lim = (0.01, 100.0, 96)
+    ctxs, bufs, frames = [], [], []
+    for ev in ([(1, 35.0, -25.0)], [(1, 80.0, -10.0)], [(1, -60.0, 30.0)], [(1, 10.0, -150.0)], [(2, -95.0, 0.0)], [(1, 200.0, 5.0)]):
+        uu, *_ = oracle.orbit_uniforms((float(W), float(H)), events=ev)
+        frames.append(uu)
+    try:
+        for i in range(F):
+            r = renderer.RayMarchingResources(0)
+            r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+            r.set_limits(lim)
+            r.set_program(cc, w)
+            ctxs.append(r)
+        bufs = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in frames]
+        for f, uu in enumerate(frames):
+            c = ctxs[f % F]
+            c.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(uu)))
+            c.draw_device(W, H, bufs[f].data_ptr(), stream=_ffi.RM_STREAM_OWN)
+        for c in ctxs:
+            c.sync_context()
+        for f, uu in enumerate(frames):
+            assert bufs[f].cpu().numpy().tobytes() == oracle.render(uu, lim, cc, w, W, H, threads=4).tobytes(), f
+    finally:
+        for c in ctxs:
+            c.close()
