@@ -53,7 +53,7 @@ def parse():
     p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ab", action="store_true", help="skip the serial and interpreter-kernel legs that follow the timed region")
-    p.add_argument("--frames-in-flight", type=int, default=2,
+    p.add_argument("--frames-in-flight", type=int, default=3,
                    help="frames drawn concurrently, each on its own context / stream / output buffer (1 = strictly serial)")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
     return p.parse_args()
@@ -119,7 +119,7 @@ def main():
     W, H = args.width, args.height
     from ray_marching_amd import shard
     tile = args.mode == "tile"
-    # Frames in flight: frame f is drawn by context f % F on stream f % F into buffer f % F (a double-buffered renderer).
+    # Frames in flight: frame f is drawn by context f % F on stream f % F into buffer f % F (a renderer with F frames in flight).
     # A frame's draw ends with a tail in which its last tiles drain and most of the chip idles; the next frame's
     # launches fill it.  F = 1 is the strictly serial loop.  (Tile mode gathers every frame: serial by nature.)
     F = 1 if tile else max(1, args.frames_in_flight)
