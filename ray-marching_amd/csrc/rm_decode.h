@@ -17,7 +17,18 @@ struct RmDecoded {
     uint32_t n_sphere = 0, n_box = 0;  // cone / slab entries of the miss-test tables; RmRecord::p[6] = slot
     uint32_t n_plane = 0;              // unbounded primitives: they veto miss-ray culling
     bool has_extensions = false;       // uses node types the reference does not implement
-    double smooth_slack = 0.0;         // sum of k/4 over SmoothUnion operators
+    // How far SmoothUnion operators can pull the tree value below the minimum over its leaves: the miss tests and
+    // the pixel-cone pre-pass inflate every bound by it.  Tracked per value-stack entry while decoding (slack[]):
+    //   leaf 0;  min / max(a,-b) / max(a,b): max(S_a, S_b);  value * s (ScalePop): S * |s|;
+    //   smin_k(a, b) with one operand exact (S = 0):  max(S_other, k)      [*]
+    //   smin_k(a, b) with both inexact:               max(S_a, S_b) + k/4
+    // [*] a chain a_0 ~ a_1 ~ a_2 ... of smooth unions never falls more than max k below the smallest operand:
+    //     with acc >= M - K (K >= k), b >= B exactly and d = |acc - b| < k, the result min(acc,b) - (k-d)^2/(4k)
+    //     is >= min(M,B) - K in each of the three cases (b the new minimum: d + (k-d)^2/4k <= k; acc still below
+    //     M: the gap g = M - acc < d, so g + (k-d)^2/4k < g + (k-g)^2/4k <= k; b < acc: only k/4 is lost).
+    //     The first version charged k/4 per operator, 3.75 for the 15-operator chain of the smooth-min test scene
+    //     instead of 0.25, which inflated every bounding sphere past its neighbours and disabled most of the culling.
+    double smooth_slack = 0.0;
     // Far-primitive pruning in specialised kernels (rm_kernel_v5.h "Pruning"): allowed when every node is a
     // 1-Lipschitz leaf or a min/max operator; scene_scale = 1 + max over primitives of |centre|_1 + |size|_1
     bool prunable = true;
@@ -56,6 +67,17 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
         }
     }
     std::vector<RmXformScope> scopes;
+    std::vector<double> slack;  // per value-stack entry, see RmDecoded::smooth_slack
+    auto combine = [&](uint32_t op_mode, double k) {  // pops b and a, pushes the operator's slack
+        const double sb = slack.back(); slack.pop_back();
+        const double sa = slack.back(); slack.pop_back();
+        double sv = sa > sb ? sa : sb;
+        if (op_mode == RM_MODE_SMOOTH) {
+            if (k > 0.0) sv = (sa == 0.0 || sb == 0.0) ? (sv > k ? sv : k) : sv + 0.25 * k;
+            else if (!(k <= 0.0)) sv = 1.0 / 0.0;  // NaN k: nothing can be bounded
+        }
+        slack.push_back(sv);
+    };
     for (uint32_t i = 0; i < cmd_count; i++) {
         if (ptr >= cap_words) return RM_ERR_TRUNCATED;
         uint32_t op = words[ptr++];
@@ -92,6 +114,7 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             if (scopes.empty() || scopes.back().op + 1u != op || depth != scopes.back().depth + 1u) return RM_ERR_TRANSFORM;
             const uint32_t level = (uint32_t)scopes.size() - 1u;
             r.p[0] = (float)scopes.back().p[0];  // ScalePop multiplies the child's value by its push's scale
+            if (op == RM_CMD_SCALE_POP && !slack.empty()) slack.back() *= std::fabs(scopes.back().p[0]);
             std::memcpy(&r.p[6], &level, 4);
             scopes.pop_back();
             r.op = RM_OP(RM_KIND_XFORM, op == RM_CMD_TRANSLATION_POP ? RM_XF_T_POP : op == RM_CMD_ROTATION_POP ? RM_XF_R_POP : RM_XF_S_POP, 0);
@@ -159,7 +182,9 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
                 else if (words[ptr] == RM_CMD_SUBTRACTION) mode = RM_MODE_SUB;
                 else if (words[ptr] == RM_CMD_INTERSECTION) { mode = RM_MODE_INTER; d.has_extensions = true; }
             }
+            slack.push_back(0.0);
             if (mode != RM_MODE_PUSH) {
+                combine(mode, 0.0);
                 ptr++;  // consume the operator: depth is unchanged (push, then pop 2 push 1)
                 i++;
                 if (depth + 1 > 32) return RM_ERR_STACK_OVERFLOW;  // the reference machine peaks one higher
@@ -182,12 +207,11 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
                 if (ptr + 1 > cap_words) return RM_ERR_TRUNCATED;
                 std::memcpy(&r.p[0], words + ptr, 4);
                 ptr += 1;
-                if (r.p[0] > 0.0f) d.smooth_slack += (double)r.p[0] * 0.25;
-                else if (!(r.p[0] <= 0.0f)) d.smooth_slack = 1.0 / 0.0;  // NaN k: nothing can be bounded
             }
             if (op == RM_CMD_INTERSECTION || op == RM_CMD_SMOOTH_UNION) d.has_extensions = true;
             if (op == RM_CMD_SMOOTH_UNION) d.prunable = false;  // not a lattice operator
             if (depth < 2) return RM_ERR_STACK_UNDERFLOW;
+            combine(mode, (double)r.p[0]);
             depth--;
             spilled--;
             r.op = RM_OP(RM_KIND_POP, mode, 0);
@@ -198,6 +222,7 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
     }
     if (!scopes.empty()) return RM_ERR_TRANSFORM;
     if (cmd_count && depth < 1) return RM_ERR_EMPTY_RESULT;
+    for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     d.n_words = ptr;
     *out = std::move(d);
     return RM_OK;

@@ -685,3 +685,50 @@ def test_frames_in_flight_on_context_owned_streams(oracle):
     finally:
         for c in ctxs:
             c.close()
+
+
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5_lds", "v5_spec"])
+def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
+    """The miss tests inflate every bound by how far SmoothUnion can pull the tree below its leaves (rm_decode.h:
+    max k for a chain, + k/4 where two blended sub-trees meet).  Worst cases: many leaves at the SAME distance from
+    one point, blended with a large k, grow a blob where no primitive is; culling must not remove the rays that hit
+    it.  Chains, balanced trees, mixed k, a scaled chain."""
+    import math
+    W, H = 72, 48
+
+    def ring(t, n, radius, r, y=0.0):
+        return [t.sphere((radius * math.cos(2 * math.pi * i / n), y, radius * math.sin(2 * math.pi * i / n)), r) for i in range(n)]
+
+    def chain(t, leaves, k):
+        acc = leaves[0]
+        for j, leaf in enumerate(leaves[1:]):
+            acc = t.smooth_union(acc, leaf, k[j % len(k)] if isinstance(k, (list, tuple)) else k)
+        return acc
+
+    def balanced(t, level, k):
+        while len(level) > 1:
+            level = [t.smooth_union(level[i], level[i + 1], k) for i in range(0, len(level), 2)]
+        return level[0]
+
+    cases = {}
+    t = scenes._Tab(); cases["ring_chain_k1.2"] = (t.nodes, chain(t, ring(t, 8, 1.0, 0.3), 1.2))
+    t = scenes._Tab(); cases["ring_chain_mixed_k"] = (t.nodes, chain(t, ring(t, 12, 1.3, 0.25), [0.2, 1.5, 0.6]))
+    t = scenes._Tab(); cases["ring_balanced_k0.9"] = (t.nodes, balanced(t, ring(t, 8, 1.0, 0.3), 0.9))
+    t = scenes._Tab(); cases["two_rings_blended"] = (t.nodes, t.smooth_union(chain(t, ring(t, 6, 0.9, 0.25, 0.4), 0.8),
+                                                                               chain(t, ring(t, 6, 0.9, 0.25, -0.4), 0.8), 1.0))
+    t = scenes._Tab(); cases["scaled_chain"] = (t.nodes, t.scale(chain(t, ring(t, 8, 1.0, 0.3), 1.2), 1.7))
+    res.resize_command_buffer(4096)
+    for name, (nodes, root) in cases.items():
+        cc, w = oracle.serialize(nodes, root)
+        for events in (scenes.STILL_CAMERA_EVENTS, [(1, 10.0, -150.0)], [(1, 35.0, -25.0), (2, 120.0, 0.0)]):
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+            for lim in [(0.01, 100.0, 96), (0.3, 100.0, 48)]:
+                ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+                setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+                res.set_option(_ffi.RM_OPT_CULL, 0)
+                off = res.draw(W, H)
+                res.set_option(_ffi.RM_OPT_CULL, 1)
+                on = res.draw(W, H)
+                assert off.tobytes() == ref.tobytes(), (name, events, lim, "cull off")
+                assert on.tobytes() == ref.tobytes(), (name, events, lim, "cull on")
+    res.resize_command_buffer(1024)
