@@ -233,6 +233,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
          "#define uint8_t rm_rtc_u8\n#define uint16_t rm_rtc_u16\n#define uint32_t rm_rtc_u32\n#define uint64_t rm_rtc_u64\n"
          "#define int32_t rm_rtc_i32\n#define int64_t rm_rtc_i64\n";
     s += "#define RM_JIT_TU 1\n";
+    if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
     if (const char* pr = std::getenv("RM_JIT_PRIO_LONG_RAYS")) {  // experiment knob
         s += "#define RM_PRIO_LONG_RAYS ";
         s += std::to_string(std::atoi(pr));

@@ -241,6 +241,26 @@ struct V5Work {
                             //                 bits of f0 = map_scene(ro) (the shared first march step), unused}
 };
 
+// b for the lanes whose bit is set in the wave mask m, a for the others: one v_cndmask_b32 with the mask as its
+// scalar operand.
+RM_DEV float select_by_mask(float a, float b, unsigned long long m) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+RM_DEV uint32_t select_by_mask(uint32_t a, uint32_t b, unsigned long long m) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+// this lane's bit of a wave mask as a predicate
+RM_DEV bool lane_of(unsigned long long m, uint32_t lane) {
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(m));
+    (void)lane;
+    return r != 0u;
+}
+
 // Persistent workgroups: the grid holds about as many workgroups as the chip has room for; each
 // takes the next tile of the work list with one atomic and leaves when the list is exhausted
 // (no spinning, no inter-workgroup dependency).  Tiles whose 1024 rays are all culled never reach
@@ -484,16 +504,20 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         }
 
         // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
-        const bool hit = is_live && sd < L.min_dist;                // wgsl:97
-        const bool esc = is_live && !hit && sd > L.max_dist;        // wgsl:109-111
-        const bool go = is_live && !hit && !esc;
-        if (go) {
-            sc += sd;  // wgsl:114
-            it += 1u;
-            if constexpr (SPEC) thr_base = __builtin_fabsf(sd) * 2.00002f;  // the next point is |sd| |rd| away
-        }
-        const bool miss = esc || (go && it >= L.max_iter);          // loop bound, wgsl:90
-        const unsigned long long hit_mask = __ballot(hit), miss_mask = __ballot(miss);
+        // Written on wave masks (64-bit scalars) with explicit selects: left to itself the compiler turned the lane
+        // predicates into 0/1 integers and back (17 vector instructions for what takes 7).
+        const unsigned long long live_m = __ballot(is_live);
+        const unsigned long long hit_mask = live_m & __ballot(sd < L.min_dist);                       // wgsl:97
+        const unsigned long long on_m = live_m & ~hit_mask;                                           // (a NaN is not a hit)
+        const unsigned long long esc_m = on_m & __ballot(sd > L.max_dist);                            // wgsl:109-111
+        const unsigned long long go_m = on_m & ~esc_m;
+        sc = select_by_mask(sc, sc + sd, go_m);                                                       // wgsl:114
+        it = select_by_mask(it, it + 1u, go_m);
+#ifdef RM_JIT_PRUNE_ON  // only pruned kernels read it
+        thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
+#endif
+        const unsigned long long miss_mask = esc_m | (go_m & __ballot(it >= L.max_iter));             // loop bound, wgsl:90
+        const bool hit = is_live && sd < L.min_dist, miss = lane_of(miss_mask, lane);
         if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
             if (hit) {
                 const uint32_t e = hq_n + lane_rank(hit_mask);
