@@ -186,6 +186,12 @@ def main():
 
     total = args.warmup + args.steps
     unis = [uniforms_for(s) for s in range(total)]
+    # set-up, not a step: every context draws once so that its scratch buffers exist and the scene's kernel is compiled
+    # and loaded before anything is timed, however small --warmup is
+    for i in range(F):
+        ctxs[i].set_uniforms(unis[0])
+        draw(i)
+    torch.cuda.synchronize()
 
     def timed_run(n_ctx):
         """W warm-up + K timed steps over the first n_ctx contexts.  Returns (seconds, mean per-draw ms from events,
