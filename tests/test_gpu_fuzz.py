@@ -1,0 +1,83 @@
+"""Seeded random CSG programs -- every node type, random nesting, degenerate parameters -- through the interpreter
+kernel, the specialised kernel and the miss tests, against the oracle.  Exercises what the hand-written scenes do not:
+arbitrary mixes of fused / unfused operators, spills, transform scopes around sub-trees, slack bookkeeping."""
+import math
+
+import numpy as np
+import pytest
+
+import scenes
+from ray_marching_amd import _ffi, renderer
+
+pytestmark = pytest.mark.gpu
+
+
+def random_tree(rng, t, depth, allow_plane):
+    """Returns a node index of a random sub-tree built into table t."""
+    r = rng.random()
+    if depth == 0 or r < 0.28:
+        kind = rng.integers(0, 4 if allow_plane else 3)
+        c = rng.uniform(-1.6, 1.6, 3)
+        if kind == 0:
+            return t.sphere(tuple(c), float(rng.choice([rng.uniform(0.2, 0.8), 0.0, -0.3, 1e-4], p=[0.85, 0.05, 0.05, 0.05])))
+        if kind == 1:
+            return t.box(tuple(c), tuple(rng.uniform(0.1, 0.7, 3) * rng.choice([1.0, 0.0, -1.0], p=[0.9, 0.05, 0.05])))
+        if kind == 2:
+            return t.cylinder(tuple(c), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.1, 0.8)))
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        return t.plane(tuple(n), float(rng.uniform(0.5, 2.0)))
+    if r < 0.50:   # a transform around a sub-tree
+        child = random_tree(rng, t, depth - 1, allow_plane)
+        k = rng.integers(0, 3)
+        if k == 0:
+            return t.translation(child, tuple(rng.uniform(-0.8, 0.8, 3)))
+        if k == 1:
+            ax = rng.normal(size=3)
+            ax /= np.linalg.norm(ax)
+            ang = rng.uniform(-math.pi, math.pi)
+            return t.rotation(child, (math.cos(ang / 2), *(math.sin(ang / 2) * ax)))
+        return t.scale(child, float(rng.uniform(0.5, 1.8)))
+    a = random_tree(rng, t, depth - 1, allow_plane)
+    b = random_tree(rng, t, depth - 1, allow_plane)
+    op = rng.choice(["u", "s", "i", "m"], p=[0.45, 0.25, 0.1, 0.2])
+    if op == "m":
+        return t.smooth_union(a, b, float(rng.choice([rng.uniform(0.05, 0.9), 0.0, -0.2], p=[0.9, 0.05, 0.05])))
+    return t.op({"u": scenes.UNION, "s": scenes.SUBTRACTION, "i": scenes.INTERSECTION}[op], a, b)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_programs_against_the_oracle(oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    W, H = 48, 32
+    res = renderer.RayMarchingResources(0)
+    try:
+        res.resize_command_buffer(8192)
+        for _ in range(3):
+            t = scenes._Tab()
+            root = random_tree(rng, t, int(rng.integers(1, 5)), allow_plane=bool(rng.random() < 0.3))
+            cc, w = oracle.serialize(t.nodes, root)
+            rc, _ = oracle.validate(cc, w)
+            prc, _ = renderer.validate_program(cc, w)
+            assert rc == prc
+            if rc != 0:      # e.g. nested more than 8 transforms deep / value stack too deep: both sides must agree
+                continue
+            events = [(1, float(rng.uniform(-300, 300)), float(rng.uniform(-140, 140))), (2, float(rng.uniform(-60, 150)), 0.0)]
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+            lim = (float(rng.choice([0.01, 0.2])), 100.0, int(rng.choice([24, 64])))
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            res.set_limits(lim)
+            res.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+            res.set_program(cc, w)
+            for spec in (0, 2):
+                res.set_option(_ffi.RM_OPT_SPECIALIZE, spec)
+                for cull in (0, 1):
+                    res.set_option(_ffi.RM_OPT_CULL, cull)
+                    img = res.draw(W, H)
+                    if img.tobytes() != ref.tobytes():
+                        bad = np.argwhere((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1))
+                        raise AssertionError("seed %d: specialise=%d cull=%d differs from the oracle at %d pixels (first %s); "
+                                             "program: cmd_count %d words %s" % (seed, spec, cull, len(bad), bad[:3].tolist(), cc,
+                                                                               [int(x) for x in w]))
+    finally:
+        res.close()

@@ -55,3 +55,29 @@ def test_mt_equals_single_thread(oracle):
     assert a.tobytes() == b.tobytes() and ca == cb
     assert ca["rays"] == 64 * 48 * 16 and ca["normal_taps"] == 4 * ca["hits"]
     assert ca["hits"] + ca["floor_hits"] + ca["sky"] == ca["rays"]
+
+
+def test_random_programs_c_equals_numpy(oracle):
+    """The C oracle and the independent numpy restatement on seeded random trees of every node type (generator shared
+    with tests/test_gpu_fuzz.py): map_scene bit for bit at random points."""
+    import numpy as np
+    from oracle import rm_oracle_np as onp
+    import scenes
+    from test_gpu_fuzz import random_tree
+    rng = np.random.default_rng(77)
+    checked = 0
+    for _ in range(60):
+        t = scenes._Tab()
+        root = random_tree(rng, t, int(rng.integers(1, 5)), allow_plane=bool(rng.random() < 0.3))
+        cc, w = oracle.serialize(t.nodes, root)
+        if oracle.validate(cc, w)[0] != 0:
+            continue
+        P = rng.uniform(-3, 3, size=(40, 3)).astype(np.float32)
+        with np.errstate(all="ignore"):
+            got = onp.map_scene(cc, w, 100.0, P[:, 0].copy(), P[:, 1].copy(), P[:, 2].copy())
+        for i in range(len(P)):
+            want = np.float32(oracle.map_scene(cc, w, [float(P[i, 0]), float(P[i, 1]), float(P[i, 2])]))
+            a, b = np.float32(got[i]), want
+            assert (np.isnan(a) and np.isnan(b)) or a.tobytes() == b.tobytes(), (cc, list(map(int, w)), P[i].tolist(), a, b)
+        checked += 1
+    assert checked >= 40
