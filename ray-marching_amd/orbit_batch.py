@@ -69,6 +69,26 @@ def write_frame(out_dir, f, img, fmt):
     return p
 
 
+def check_manifest(args):
+    """Resume is by frame index and file size only, so the directory must belong to the same job: the first run writes
+    orbit.json, later runs refuse to mix parameters (a different frame count changes every camera)."""
+    want = {"frames": args.frames, "width": args.width, "height": args.height, "scene": args.scene,
+            "max_iter": args.max_iter, "format": args.format}
+    path = os.path.join(args.out_dir, "orbit.json")
+    try:
+        with open(path) as fh:
+            have = json.load(fh)
+    except (OSError, ValueError):
+        have = None
+    if have is None:
+        tmp = path + ".part%d" % os.getpid()
+        with open(tmp, "w") as fh:
+            json.dump(want, fh)
+        os.replace(tmp, path)
+    elif have != want:
+        raise SystemExit("%s was written with %s; this run asks for %s" % (args.out_dir, have, want))
+
+
 def orbit_yaw(f, n_frames):
     return 2.0 * math.pi * f / n_frames
 
@@ -80,6 +100,7 @@ def render_batch(args, rank=0, world=1, device=0, log=None):
 
     W, H = args.width, args.height
     os.makedirs(args.out_dir, exist_ok=True)
+    check_manifest(args)
     todo = frames_todo(args.out_dir, args.frames, rank, world, W, H, args.format)
     mine = len(shard.frames_of_rank(args.frames, rank, world))
     summary = {"rank": rank, "frames_assigned": mine, "frames_skipped": mine - len(todo), "frames_rendered": 0,

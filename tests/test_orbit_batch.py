@@ -34,6 +34,13 @@ def test_ppm_files_and_resume_logic(tmp_path):
     q = orbit_batch.write_frame(out, 2, f32, "f32")
     assert np.array_equal(np.fromfile(q, dtype=np.float32).reshape(H, W, 4), f32)
     assert math.isclose(orbit_batch.orbit_yaw(256, 1024), math.pi / 2)
+    # a directory belongs to one job: the manifest refuses other parameters
+    a = _args(tmp_path / "job")
+    os.makedirs(a.out_dir)
+    orbit_batch.check_manifest(a)
+    orbit_batch.check_manifest(a)
+    with pytest.raises(SystemExit):
+        orbit_batch.check_manifest(_args(tmp_path / "job", frames=7))
 
 
 def _args(out_dir, **kw):
