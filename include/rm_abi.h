@@ -209,6 +209,10 @@ int rm_draw_batch(rm_ctx* ctx, const rm_uniforms* frames, uint32_t n_frames, uin
 
 /* Waits for all work on the context's GPU (hipDeviceSynchronize). */
 int rm_sync(rm_ctx* ctx);
+/* HIP graphs: after its first draw of a given size and program (which allocates scratch buffers and compiles /
+ * loads the scene's kernel), a device-destination rm_draw issues nothing but kernel launches on `stream` -- no
+ * allocation, copy, event or synchronisation (RM_OPT_TIMING off) -- and can be stream-captured and replayed
+ * (tests: test_draw_is_stream_capturable).  The uniforms travel as kernel arguments, i.e. are baked into the graph. */
 /* Frames in flight without creating HIP streams in the host language: pass RM_STREAM_OWN as `stream` of a
  * device-destination draw and the launches go to the context's own stream; rm_sync_context waits for that stream
  * only.  A host that alternates two or three contexts this way (frame f -> context f % F, each with its own output

@@ -732,3 +732,36 @@ def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
                 assert off.tobytes() == ref.tobytes(), (name, events, lim, "cull off")
                 assert on.tobytes() == ref.tobytes(), (name, events, lim, "cull on")
     res.resize_command_buffer(1024)
+
+
+def test_draw_is_stream_capturable(oracle):
+    """After its first (allocating, compiling) draw of a size, rm_draw with a device destination issues nothing but
+    kernel launches on the caller's stream: it can be captured into a HIP graph and replayed."""
+    import torch
+    W, H = 96, 64
+    cc, w = oracle.serialize(*scenes.g32())
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    lim = (0.01, 100.0, 96)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        r.set_program(cc, w)
+        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        r.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)       # warm: scratch buffers, compiled kernel
+        s.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            g.capture_begin()
+            r.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)
+            g.capture_end()
+        for _ in range(3):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert out.cpu().numpy().tobytes() == ref.tobytes()
+    finally:
+        r.close()
