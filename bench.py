@@ -50,7 +50,9 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", help="process-group backend for the timing barrier (nccl = RCCL)")
     p.add_argument("--all-ranks-on-device0", action="store_true",
                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
-    p.add_argument("--gather", action="store_true", help="tile mode: include the host-side gather in the timed region")
+    p.add_argument("--gather", nargs="?", const="gloo", default=None, choices=["gloo", "shm"],
+                   help="tile mode: include the host-side gather in the timed region: gloo = gather to rank 0 over the "
+                        "process group; shm = every rank copies its strips into one shared-memory image (never RCCL)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ab", action="store_true", help="skip the serial and interpreter-kernel legs that follow the timed region")
     p.add_argument("--frames-in-flight", type=int, default=3,
@@ -165,6 +167,13 @@ def main():
     outs = [torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
     out = outs[0]
     gloo = dist.new_group(backend="gloo") if (tile and args.gather and world > 1) else None
+    shared = pinned = None
+    if tile and args.gather == "shm":
+        def host_barrier():
+            dist.barrier(group=gloo)
+        shared = shard.SharedImage("rm_bench_%s" % os.environ.get("MASTER_PORT", "0"), W, H).open(
+            rank, world, host_barrier if world > 1 else (lambda: None))
+        pinned = torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32).pin_memory()
     streams = [torch.cuda.Stream() for _ in range(F)]   # kernels, events and syncs of frame f all use stream f % F
     stream = streams[0]
     torch.cuda.set_stream(stream)
@@ -178,7 +187,14 @@ def main():
     def draw(i=0):
         if tile:
             res.draw_strips_device(W, H, shard.DEFAULT_STRIP_ROWS, rank, world, out.data_ptr(), stream=sptr)
-            if args.gather:      # final host-side gather (D2H + gloo), never RCCL
+            if args.gather == "shm":      # D2H into pinned memory, then this rank's strips go to their place in the shared frame
+                with torch.cuda.stream(stream):
+                    pinned.copy_(out, non_blocking=True)
+                stream.synchronize()
+                shared.put_strips(pinned[:my_rows].numpy(), rank, world)
+                if world > 1:
+                    dist.barrier(group=gloo)
+            elif args.gather:             # final host-side gather (D2H + gloo), never RCCL
                 stream.synchronize()
                 shard.gather_image(out[:my_rows].cpu().numpy(), W, H, rank, world, group=gloo)
         else:
@@ -274,7 +290,7 @@ def main():
                        "camera": args.camera, "kernel": args.kernel,
                        "specialized_kernel": specialized, "jit_compile_ms": jit_ms, "frames_in_flight": F,
                        "sharding": ("one frame tiled over ranks in interleaved 16-row strips%s, no collective"
-                                    % (" + host gather" if args.gather else "")) if tile
+                                    % ((" + host gather (%s)" % args.gather) if args.gather else "")) if tile
                        else ("frames over ranks, no collective" if world > 1 else "single GPU")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
@@ -308,6 +324,8 @@ def main():
         print(json.dumps(line), flush=True)
     for c in ctxs:
         c.close()
+    if shared is not None:
+        shared.close((lambda: dist.barrier(group=gloo)) if world > 1 else None)
     if world > 1:
         dist.destroy_process_group()
 

@@ -67,6 +67,58 @@ def gather_image(compact, W, H, rank, world, strip_rows=DEFAULT_STRIP_ROWS, grou
     return image
 
 
+class SharedImage:
+    """One (H, W, 4) image in POSIX shared memory that every rank of the node maps: the host-side gather of a tiled
+    frame becomes "each rank copies its own strips to their place" plus a barrier -- no rank relays another rank's
+    pixels (gather_image moves every strip twice and serialises on the destination).  Rank `dst` creates the segment,
+    the others attach after the barrier in open(); close() unlinks it on `dst`."""
+
+    def __init__(self, name, W, H, dtype=np.float32):
+        self.name, self.W, self.H, self.dtype = name, W, H, np.dtype(dtype)
+        self._shm = None
+        self.array = None
+
+    def open(self, rank, world, barrier, dst=0):
+        from multiprocessing import shared_memory
+        nbytes = self.H * self.W * 4 * self.dtype.itemsize
+        if rank == dst:
+            self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=max(nbytes, 1))
+        if world > 1:
+            barrier()
+        if rank != dst:
+            self._shm = shared_memory.SharedMemory(name=self.name)
+            try:        # the creator owns the segment; keep this process's resource tracker from unlinking it at exit
+                from multiprocessing import resource_tracker
+                resource_tracker.unregister(self._shm._name, "shared_memory")
+            except Exception:
+                pass
+        self.array = np.ndarray((self.H, self.W, 4), dtype=self.dtype, buffer=self._shm.buf)
+        self._owner = rank == dst
+        return self
+
+    def put_strips(self, compact, rank, world, strip_rows=DEFAULT_STRIP_ROWS):
+        scatter_strips(self.array, compact, self.H, rank, world, strip_rows)
+
+    def close(self, barrier=None):
+        self.array = None
+        if barrier is not None:
+            barrier()
+        if self._shm is not None:
+            self._shm.close()
+            if self._owner:
+                self._shm.unlink()
+            self._shm = None
+
+
+def render_tiled_shared(draw_strips, image, rank, world, barrier, strip_rows=DEFAULT_STRIP_ROWS):
+    """draw_strips(strip_rows, first, stride) -> compact host array, written straight into the SharedImage; after the
+    barrier every rank sees the whole frame in image.array."""
+    image.put_strips(draw_strips(strip_rows, rank, world), rank, world, strip_rows)
+    if world > 1:
+        barrier()
+    return image.array
+
+
 def render_tiled(draw_strips, W, H, rank, world, strip_rows=DEFAULT_STRIP_ROWS, group=None, dst=0):
     """draw_strips(strip_rows, first, stride) -> compact host array; returns the frame on `dst`."""
     compact = draw_strips(strip_rows, rank, world)

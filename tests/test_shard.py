@@ -62,11 +62,16 @@ def _worker(rank, world, port, W, H, q):
     img = shard.render_tiled(draw_strips, W, H, rank, world)
     frames = shard.frames_of_rank(5, rank, world)
     dist.barrier()
+    # the same frame through the shared-memory gather: every rank ends up seeing the whole image
+    shared = shard.SharedImage("rm_test_%d" % port, W, H).open(rank, world, dist.barrier)
+    whole = shard.render_tiled_shared(draw_strips, shared, rank, world, dist.barrier)
+    full = cbind.render(u, lim, cc, w, W, H)
+    same_shared = whole.tobytes() == full.tobytes()
+    shared.close(dist.barrier)
     if rank == 0:
-        full = cbind.render(u, lim, cc, w, W, H)
-        q.put((img.tobytes() == full.tobytes(), frames))
+        q.put((img.tobytes() == full.tobytes() and same_shared, frames))
     else:
-        assert img is None
+        assert img is None and same_shared
     dist.destroy_process_group()
 
 
