@@ -28,6 +28,19 @@ int main(int argc, char** argv) {
             std::fwrite(image.data(), 4, image.size(), f);
             std::fclose(f);
         }
+        // The same frame once more with the scene's specialised kernel (compiled by hipRTC in THIS process: the
+        // system ROCm, no PyTorch anywhere), waiting for the compiler: must be the same bytes.
+        resources.check(rm_set_option(resources.ctx(), RM_OPT_SPECIALIZE, 2));
+        std::vector<float> again(image.size());
+        cb.paint(resources, W, H, again.data());
+        double specialised = 0.0, jit_ms = 0.0;
+        resources.check(rm_get_info(resources.ctx(), RM_INFO_SPECIALIZED, &specialised));
+        resources.check(rm_get_info(resources.ctx(), RM_INFO_JIT_COMPILE_MS, &jit_ms));
+        if (std::memcmp(again.data(), image.data(), image.size() * 4) != 0) {
+            std::fprintf(stderr, "specialised kernel and interpreter kernel disagree\n");
+            return 4;
+        }
+        std::printf("specialised %d jit_ms %.0f\n", (int)specialised, jit_ms);
         // None scene: cmd_count = 0 (renderer.rs:224-227)
         auto none_cb = RayMarchingCallback::new_(0.0f, std::nullopt, {(float)W, (float)H}, controller.camera());
         none_cb.prepare(resources);

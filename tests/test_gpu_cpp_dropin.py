@@ -20,6 +20,7 @@ def test_cpp_dropin_program(oracle, tmp_path):
     r = subprocess.run([exe, str(out)], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr
     assert "dropin ok" in r.stdout
+    assert "specialised 1" in r.stdout, r.stdout      # hipRTC of the system ROCm compiled the scene's kernel in a pure C++ process
     W, H = 96, 64
     img = np.fromfile(out, dtype=np.float32).reshape(H, W, 4)
     cc, w = oracle.serialize(*scenes.g8())
