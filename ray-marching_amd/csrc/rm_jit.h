@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <unistd.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -51,8 +52,10 @@ struct Rtc {
     int (*GetCodeSize)(Program, size_t*) = nullptr;
     int (*GetCode)(Program, char*) = nullptr;
     int (*DestroyProgram)(Program*) = nullptr;
+    int (*Version)(int*, int*) = nullptr;
     void* handle = nullptr;
     std::string error;
+    std::string identity;  // which compiler this is: library file + version (part of the disk-cache key)
 
     static Rtc& get() {
         static Rtc r;
@@ -88,7 +91,14 @@ private:
         GetCodeSize = reinterpret_cast<decltype(GetCodeSize)>(sym("hiprtcGetCodeSize"));
         GetCode = reinterpret_cast<decltype(GetCode)>(sym("hiprtcGetCode"));
         DestroyProgram = reinterpret_cast<decltype(DestroyProgram)>(sym("hiprtcDestroyProgram"));
-        if (!all) handle = nullptr;  // the library stays mapped; it is simply not used
+        if (!all) { handle = nullptr; return; }  // the library stays mapped; it is simply not used
+        Version = reinterpret_cast<decltype(Version)>(dlsym(handle, "hiprtcVersion"));
+        int major = 0, minor = 0;
+        if (Version) (void)Version(&major, &minor);
+        Dl_info info;
+        std::memset(&info, 0, sizeof info);
+        (void)dladdr(reinterpret_cast<void*>(CreateProgram), &info);
+        identity = std::string(info.dli_fname ? info.dli_fname : "?") + ":" + std::to_string(major) + "." + std::to_string(minor);
     }
 };
 
@@ -261,6 +271,36 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
     Rtc& rtc = Rtc::get();
     if (!rtc.ok()) { *log = rtc.error; return false; }
     const auto t0 = std::chrono::steady_clock::now();
+    // Optional disk cache (RM_JIT_CACHE_DIR): code objects keyed by everything that determines them -- the generated
+    // source, the embedded headers, the compiler (library file + version).  A second process starts warm.
+    std::string cache_file;
+    if (const char* dir = std::getenv("RM_JIT_CACHE_DIR")) {
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&](const char* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } };
+        mix(src.data(), src.size());
+        for (int i = 0; i < kNumHeaders; i++) mix(kHeaderSources[i], std::strlen(kHeaderSources[i]));
+        mix(rtc.identity.data(), rtc.identity.size());
+        char name[64];
+        std::snprintf(name, sizeof name, "/rm_%016llx.co", (unsigned long long)h);
+        cache_file = std::string(dir) + name;
+        if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
+            std::fseek(f, 0, SEEK_END);
+            const long n = std::ftell(f);
+            std::fseek(f, 0, SEEK_SET);
+            bool ok = n > 64;
+            if (ok) {
+                code->resize((size_t)n);
+                ok = std::fread(code->data(), 1, (size_t)n, f) == (size_t)n && std::memcmp(code->data(), "\177ELF", 4) == 0;
+            }
+            std::fclose(f);
+            if (ok) {
+                *log = "loaded from " + cache_file;
+                if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                return true;
+            }
+            code->clear();
+        }
+    }
     Rtc::Program prog = nullptr;
     int rc = rtc.CreateProgram(&prog, src.c_str(), "rm_spec.hip", (int)kNumHeaders, kHeaderSources, kHeaderNames);
     if (rc != 0) { *log = "hiprtcCreateProgram failed: " + std::to_string(rc); return false; }
@@ -284,6 +324,14 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
         *log = "hiprtcCompileProgram failed: " + std::to_string(rc);
     }
     rtc.DestroyProgram(&prog);
+    if (ok && !cache_file.empty()) {  // write-then-rename: another process never sees half a file
+        const std::string tmp = cache_file + ".part" + std::to_string((long)getpid());
+        if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
+            const bool w = std::fwrite(code->data(), 1, code->size(), f) == code->size();
+            std::fclose(f);
+            if (!w || std::rename(tmp.c_str(), cache_file.c_str()) != 0) std::remove(tmp.c_str());
+        }
+    }
     if (const char* dir = std::getenv("RM_JIT_DUMP_DIR")) {  // diagnostics: keep what was compiled
         static std::atomic<int> serial{0};
         const std::string base = std::string(dir) + "/rm_spec_" + std::to_string(serial++);

@@ -169,3 +169,37 @@ def test_generated_kernel_compiles_for_gfx950(oracle, name, prune):
         pytest.skip("libhiprtc is not installed: " + log)
     assert rc == _ffi.RM_OK, log
     assert nbytes > 4096 and ms > 0
+
+
+def test_disk_cache_of_compiled_kernels(oracle, tmp_path):
+    """RM_JIT_CACHE_DIR: the second compilation of the same kernel by a NEW process is a file read; another structure
+    or a corrupted file is compiled afresh.  (A subprocess per step: the library reads the variable at compile time
+    and keeps no in-memory cache on this path, but a fresh process is what the cache is for.)"""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from ray_marching_amd import csg, renderer\n"
+            "cc, w = csg.serialize(csg.scene(sys.argv[1]))\n"
+            "rc, ms, n, log = renderer.jit_compile(cc, w)\n"
+            "print(rc, n, 'loaded' if 'loaded from' in log else ('nohiprtc' if 'could not be loaded' in log else 'compiled'))\n"
+            % (str(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))),
+               str(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
+    env = dict(__import__('os').environ, RM_JIT_CACHE_DIR=str(tmp_path))
+
+    def run(scene):
+        r = subprocess.run([sys.executable, "-c", code, scene], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stdout.split()
+
+    first = run("g8")
+    if first[2] == "nohiprtc":
+        pytest.skip("libhiprtc is not installed")
+    assert first[0] == "0" and first[2] == "compiled"
+    files = sorted(p.name for p in tmp_path.iterdir())
+    assert len(files) == 1 and files[0].endswith(".co")
+    second = run("g8")
+    assert second == ["0", first[1], "loaded"]
+    assert run("g32")[2] == "compiled" and len(list(tmp_path.iterdir())) == 2
+    (tmp_path / files[0]).write_bytes(b"not a code object")
+    assert run("g8")[2] == "compiled"                      # a damaged entry is ignored and replaced
+    assert (tmp_path / files[0]).read_bytes()[:4] == b"\x7fELF"
