@@ -765,3 +765,18 @@ def test_draw_is_stream_capturable(oracle):
             assert out.cpu().numpy().tobytes() == ref.tobytes()
     finally:
         r.close()
+
+
+def test_8k_config_row_bands_vs_oracle(res, oracle):
+    """BASELINE configs[3] at its full size (7680x4320, 64-node graph, 512 steps; 518 400 tiles) on the default path:
+    sampled row bands bit-exact against the oracle, alpha plane and finiteness of the whole frame."""
+    W, H = 7680, 4320
+    lim = (0.01, 100.0, 512)
+    cc, w, u = oracle_case(oracle, scenes.g64(), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim)
+    full = res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
+    assert np.isfinite(full).all() and np.array_equal(full[..., 3], np.ones((H, W), np.float32))
+    for r0, rows in [(1300, 2), (2161, 2), (3000, 1)]:
+        assert_same(full[r0:r0 + rows], oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=16))
+    del full
