@@ -64,7 +64,8 @@ struct rm_ctx {
     uint32_t refill_min = 8;
     uint32_t refill_min_v5 = 1;
     bool cull = true;
-    int balance = 1;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first
+    int balance = 3;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first,
+                      // 3 (default) longest tiles of the previous draw of the same shape first
     int waves_per_tile = 4;
     bool wave_stats = false;
     unsigned long long* d_stats = nullptr;
@@ -72,6 +73,9 @@ struct rm_ctx {
     uint32_t* d_cost = nullptr;   // per-tile cost estimates / dispatch order of the balance pre-pass
     uint32_t* d_order = nullptr;
     uint32_t* d_counters = nullptr;  // v5: {work-list length, cursor} per frame
+    uint32_t* d_measured = nullptr;  // v5, RM_OPT_BALANCE = 3: per-tile durations of the previous draw of the same shape
+    size_t d_measured_cap = 0;
+    uint64_t measured_shape = 0;     // hash of (W, rows, strips, frames) the measurements belong to; 0 = none yet
     size_t d_counters_cap = 0;
     size_t d_tiles_cap = 0;
     bool timing = false;
@@ -292,9 +296,26 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 4u)) return rc;
     hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames),
                        dim3(64u * rmk::V5_PRE_TILES), 16u + cull_bytes + (size_t)(L.n_cone + L.n_slab) * 8u, s, L, c->d_cost, n_tiles);
+    // RM_OPT_BALANCE = 3: the march kernel records how long every tile took; the next draw of the same shape
+    // dispatches the longest first (consecutive frames of an interactive view or an orbit look alike)
+    const uint32_t* prev = nullptr;
+    uint32_t* measured = nullptr;
+    if (c->balance == 3) {
+        const size_t need = (size_t)n_tiles * n_frames;
+        if (need > c->d_measured_cap) {
+            if (int rc = grow_device(c, &c->d_measured, &c->d_measured_cap, need)) return rc;
+            c->measured_shape = 0;
+        }
+        const uint64_t shape = ((uint64_t)L.W << 40) ^ ((uint64_t)L.rows << 20) ^ ((uint64_t)L.strip_rows << 12) ^
+                               ((uint64_t)L.strip_first << 6) ^ (uint64_t)L.strip_stride ^ ((uint64_t)n_frames << 52) ^ 1ull;
+        if (c->measured_shape == shape) prev = c->d_measured;
+        else HIP_TRY(c, hipMemsetAsync(c->d_measured, 0, need * sizeof(uint32_t), s));
+        c->measured_shape = shape;
+        measured = c->d_measured;
+    }
     hipLaunchKernelGGL(rmk::rm_tile_sort_v5, dim3(n_frames), dim3(1024), 0, s, L, c->d_cost, c->d_order, c->d_counters,
-                       n_tiles, (uint32_t)c->balance);
-    rmk::V5Work work{c->d_order, c->d_counters};
+                       n_tiles, (uint32_t)c->balance, prev);
+    rmk::V5Work work{c->d_order, c->d_counters, measured};
     // persistent grid: about as many workgroups as fit the chip (LDS, 32 waves per CU), never more than tiles
     uint32_t per_cu = (uint32_t)std::min<size_t>(32u / WPT, (160u * 1024u) / shmem);
     if (per_cu < 1u) per_cu = 1u;
@@ -541,6 +562,7 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_cost) (void)hipFree(c->d_cost);
     if (c->d_order) (void)hipFree(c->d_order);
     if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->d_measured) (void)hipFree(c->d_measured);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
     for (auto& e : c->tev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -747,7 +769,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_TIMING: c->timing = value != 0; c->tev_used = 0; return RM_OK;
     case RM_OPT_STRICT_CAP: return RM_OK;
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
-    case RM_OPT_BALANCE: c->balance = value < 0 ? 0 : value > 2 ? 2 : (int)value; return RM_OK;
+    case RM_OPT_BALANCE: c->balance = value < 0 ? 0 : value > 3 ? 3 : (int)value; c->measured_shape = 0; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
     case RM_OPT_PRUNE: c->prune = value != 0; c->spec_gen = ~0ull; return RM_OK;
     case RM_OPT_OUTPUT_FORMAT:

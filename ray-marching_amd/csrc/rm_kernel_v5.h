@@ -239,6 +239,8 @@ struct V5Work {
     const uint32_t* order;  // [n_frames][n_tiles] ids of the tiles that need marching, heaviest first
     uint32_t* counters;     // [n_frames][4]: {number of such tiles, cursor of the persistent workgroups,
                             //                 bits of f0 = map_scene(ro) (the shared first march step), unused}
+    uint32_t* measured;     // nullptr, or [n_frames][n_tiles]: how long each marched tile took (10 ns ticks), written here
+                            // and read by the NEXT draw's rm_tile_sort_v5 (RM_OPT_BALANCE = 3: longest tiles first)
 };
 
 // b for the lanes whose bit is set in the wave mask m, a for the others: one v_cndmask_b32 with the mask as its
@@ -361,6 +363,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const uint32_t tile = order[slot];
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     n_tiles_done++;
+    const unsigned long long tile_t0 = work.measured ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
     // Ray r of the pool: pixel r & 63 (== this lane in a produce round), AA sample r >> 6.
     const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
@@ -566,6 +569,10 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             store_pixel(L, blockIdx.z, (size_t)py * L.W + px, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75
         }
     }
+    if (work.measured && tid == 0u) {
+        const unsigned long long dt = __builtin_amdgcn_s_memrealtime() - tile_t0;
+        work.measured[(size_t)blockIdx.z * n_tiles + tile] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (dt == 0ull ? 1u : (uint32_t)dt);
+    }
     __syncthreads();  // res[] / rings / cursor are reused by the next tile
   }
     if (L.stats && lane == 0u) {
@@ -734,8 +741,18 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
 // Work list of one frame (blockIdx.x = frame): ids of the tiles with cost > 0, by descending cost
 // when `balance` is set.  Also resets the persistent kernel's cursor.
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
+// With `prev` (what the previous draw of the same shape measured per tile) the key of a tile that was marched then is
+// its duration on a 4-steps-per-octave log scale, so that the LONGEST tiles are dispatched first and the kernel ends
+// on its shortest ones; a tile without a measurement keeps its pending-pixel count (64 for a fully covered tile, i.e.
+// it is treated as heavy).  The order only affects when a tile is rendered, never its pixels.
+RM_DEV uint32_t duration_key(uint32_t ticks) {  // 1..64; 64 ticks (0.64 us) -> 1, doubling adds 4
+    if (ticks < 64u) return 1u;
+    const uint32_t lz = 31u - (uint32_t)__builtin_clz(ticks);
+    const uint32_t q = 4u * lz + ((ticks >> (lz - 2u)) & 3u) - 23u;
+    return q > 64u ? 64u : q;
+}
 __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32_t* cost, uint32_t* order, uint32_t* counters,
-                                                        uint32_t n_tiles, uint32_t balance) {
+                                                        uint32_t n_tiles, uint32_t balance, const uint32_t* prev) {
     __shared__ uint32_t hist[65], base[65];
     __shared__ float f0_spill[(32 + 3 * RM_MAX_XFORM_DEPTH) * 64];
     const uint32_t tid = threadIdx.x;
@@ -754,14 +771,23 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32
         if (tid == 960u) counters[4u * blockIdx.x + 2u] = __float_as_uint(v[0]);
     }
     const uint32_t* c = cost + (size_t)blockIdx.x * n_tiles;
+    const uint32_t* pm = prev ? prev + (size_t)blockIdx.x * n_tiles : nullptr;
     uint32_t* o = order + (size_t)blockIdx.x * n_tiles;
+    auto key_of = [&](uint32_t i) -> uint32_t {
+        uint32_t v = i < n_tiles ? c[i] : 0u;
+        if (pm && v != 0u) {
+            const uint32_t t = pm[i];
+            if (t != 0u) v = duration_key(t);
+        }
+        return v;
+    };
     if (tid < 65u) hist[tid] = 0u;
     __syncthreads();
     // bucket 0 = heaviest (cost 64) ... bucket 63 = cost 1; cost 0 (finished in the pre-pass) is dropped
     auto bucket = [&](uint32_t v) { return balance ? 64u - (v < 64u ? v : 64u) : 0u; };
     for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u) {
         const uint32_t i = i0 + tid;
-        const uint32_t v = i < n_tiles ? c[i] : 0u;
+        const uint32_t v = key_of(i);
         // most active tiles have the same cost (64): count those once per wave, not once per lane
         const unsigned long long heavy = __ballot(v != 0u && bucket(v) == 0u);
         if (heavy != 0ull && (tid & 63u) == (uint32_t)__builtin_ctzll(heavy)) atomicAdd(&hist[0], (uint32_t)__popcll(heavy));
@@ -783,7 +809,7 @@ __global__ __launch_bounds__(1024) void rm_tile_sort_v5(RmLaunch L, const uint32
     __syncthreads();
     for (uint32_t i0 = 0; i0 < n_tiles; i0 += 1024u) {
         const uint32_t i = i0 + tid;
-        const uint32_t v = i < n_tiles ? c[i] : 0u;
+        const uint32_t v = key_of(i);
         const bool is_heavy = v != 0u && bucket(v) == 0u;
         const unsigned long long heavy = __ballot(is_heavy);
         uint32_t pos0 = 0u;
