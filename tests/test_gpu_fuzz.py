@@ -46,7 +46,12 @@ def random_tree(rng, t, depth, allow_plane):
     return t.op({"u": scenes.UNION, "s": scenes.SUBTRACTION, "i": scenes.INTERSECTION}[op], a, b)
 
 
-@pytest.mark.parametrize("seed", range(24))
+import os
+
+SEEDS = range(int(os.environ.get("RM_FUZZ_FIRST_SEED", "0")), int(os.environ.get("RM_FUZZ_FIRST_SEED", "0")) + int(os.environ.get("RM_FUZZ_SEEDS", "24")))
+
+
+@pytest.mark.parametrize("seed", SEEDS)
 def test_random_programs_against_the_oracle(oracle, seed):
     rng = np.random.default_rng(1000 + seed)
     W, H = 48, 32
