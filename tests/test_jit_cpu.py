@@ -31,6 +31,7 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "const float v1 = vmin(v0, spec_box<FAST>(lp + 9, x0, y0, z0, tiny));",
         "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 17, x0, y0, z0, tiny));",
         "const float v3 = vmin(v2, spec_box<FAST>(lp + 25, x0, y0, z0, tiny));",
+        "__builtin_amdgcn_sched_barrier(0);",
         "return v3;",
     ]
     body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True))]
@@ -49,6 +50,7 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "float v3 = v2;",
         "{ const SpecBox b = spec_box_a(lp + 25, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
+        "__builtin_amdgcn_sched_barrier(0);",
         "return v3;",
     ]
 
@@ -72,7 +74,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
     pending = None
     for line in body:
         line = line.strip()
-        if line.startswith("const float thr") or line.startswith("const float inf") or line.startswith("const float x0"):
+        if line.startswith(("const float thr", "const float inf", "const float x0", "__builtin_amdgcn_sched_barrier")):
             continue
         if line.startswith("return"):
             return env[line.rstrip(";").split()[1]]
