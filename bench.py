@@ -307,6 +307,16 @@ def main():
                                  "bound by ~3 orders of magnitude, see `compute`"},
             "checksum_rgb": checksum,
         }
+        if world == 1:
+            # the measured HBM-write ceiling of this GPU, same run: a fill kernel with 16 B/lane stores over 1 GiB
+            # (SURVEY 8(d)); the declared peak above stays the spec figure
+            try:
+                fill = res.measure_write_bandwidth(1 << 30, 10)
+                line["roofline"]["measured_write_GBps"] = fill
+                line["roofline"]["frac_of_measured"] = ach / fill if fill > 0 else None
+            except Exception as e:      # diagnostics only
+                line["roofline"]["measured_write_GBps"] = None
+                line["roofline"]["measured_write_error"] = str(e)
         if serial is not None:
             line["one_frame_in_flight"] = serial
         if ab is not None:
