@@ -24,7 +24,12 @@
  * An rm_ctx is bound to one GPU and is externally synchronised (one thread at a time);
  * different contexts may be used concurrently from different threads/processes.  Asynchronous
  * (device-destination) draws of ONE context share its scratch buffers: issue them on one stream,
- * or wait for a draw before issuing the next on another stream.
+ * or wait for a draw before issuing the next on another stream.  Buffer writes are ordered with the
+ * draws like queue.write_buffer is in wgpu (renderer.rs:213-239): limits and uniforms travel with each
+ * draw as kernel arguments; a changed program (and the cameras of rm_draw_batch) is copied to the GPU on
+ * the stream of the next draw, behind the draws already queued there, so a frame that is still in flight
+ * keeps the program it was issued with.  Rewriting the command buffer with the bytes it already holds
+ * (the reference does so every frame, renderer.rs:224-239) costs a memcmp and no decode or copy.
  *
  * Output image: RGBA32F, 16 bytes per pixel, row-major, top row first (framebuffer
  * orientation); pixel (px,py) has pt_screen = (-1 + 2(px+.5)/W, 1 - 2(py+.5)/H), the

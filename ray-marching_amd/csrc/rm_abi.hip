@@ -90,6 +90,10 @@ struct rm_ctx {
     uint64_t spec_gen = ~0ull;
     int spec_wpt = 0;
     bool last_specialized = false;  // the last march launch ran a specialised kernel
+    // stream-ordered uploads (program records, bounds, batch uniforms): four pinned staging buffers, see upload()
+    struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
+    Staging staging[4];
+    unsigned staging_next = 0;
     std::string err;
 };
 
@@ -114,7 +118,37 @@ int fail(rm_ctx* c, int status, const char* fmt, ...) {
                         __FILE__, __LINE__);                                                       \
     } while (0)
 
-int ensure_program(rm_ctx* c) {
+// Host data -> device scratch of the context, ordered on the stream the next draw is issued on (what
+// queue.write_buffer is to wgpu, renderer.rs:213-239): a draw of the previous program that is still queued or
+// running on `s` keeps reading the previous contents, and the caller's memory is free again when this returns.
+// The bytes wait in one of four pinned staging buffers; only a fifth upload with the first still pending blocks.
+int upload(rm_ctx* c, void* dst, const void* src, size_t bytes, hipStream_t s) {
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &capturing) != hipSuccess) (void)hipGetLastError();
+    else if (capturing != hipStreamCaptureStatusNone)
+        return fail(c, RM_ERR_ARG, "the program or batch changed during stream capture: draw once before capturing");
+    rm_ctx::Staging& st = c->staging[c->staging_next++ & 3u];
+    if (st.pending) {
+        HIP_TRY(c, hipEventSynchronize(st.done));
+        st.pending = false;
+    }
+    if (bytes > st.cap) {
+        if (st.host) (void)hipHostFree(st.host);
+        st.host = nullptr;
+        st.cap = 0;
+        const size_t cap = std::max<size_t>(4096, bytes + bytes / 2);
+        HIP_TRY(c, hipHostMalloc(&st.host, cap, hipHostMallocDefault));
+        st.cap = cap;
+    }
+    if (!st.done) HIP_TRY(c, hipEventCreateWithFlags(&st.done, hipEventDisableTiming));
+    std::memcpy(st.host, src, bytes);
+    HIP_TRY(c, hipMemcpyAsync(dst, st.host, bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(c, hipEventRecord(st.done, s));
+    st.pending = true;
+    return RM_OK;
+}
+
+int ensure_program(rm_ctx* c, hipStream_t s) {
     if (!c->cmd_dirty) return c->cmd_status;
     c->cmd_dirty = false;
     const uint32_t cap_words = (uint32_t)c->cmd.size() - 1u;
@@ -137,11 +171,9 @@ int ensure_program(rm_ctx* c) {
         c->d_prog_cap = cap;
     }
     if (!d.rec.empty()) {
-        // Synchronous copy from pageable memory: complete before the next launch on any stream.
-        hipError_t e = hipMemcpy(c->d_prog, d.rec.data(), d.rec.size() * sizeof(RmRecord), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
+        if (int urc = upload(c, c->d_prog, d.rec.data(), d.rec.size() * sizeof(RmRecord), s)) {
             c->cmd_dirty = true;
-            return fail(c, RM_ERR_DEVICE, "hipMemcpy(program) failed: %s", hipGetErrorString(e));
+            return urc;
         }
     }
     if (!d.bounds.empty()) {
@@ -157,10 +189,9 @@ int ensure_program(rm_ctx* c) {
             }
             c->d_bounds_cap = std::max<size_t>(64, 2 * n);
         }
-        hipError_t e = hipMemcpy(c->d_bounds, d.bounds.data(), d.bounds.size() * sizeof(float), hipMemcpyHostToDevice);
-        if (e != hipSuccess) {
+        if (int urc = upload(c, c->d_bounds, d.bounds.data(), d.bounds.size() * sizeof(float), s)) {
             c->cmd_dirty = true;
-            return fail(c, RM_ERR_DEVICE, "hipMemcpy(bounds) failed: %s", hipGetErrorString(e));
+            return urc;
         }
     }
     c->decoded = std::move(d);
@@ -564,6 +595,10 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_measured) (void)hipFree(c->d_measured);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
+    for (auto& st : c->staging) {
+        if (st.host) (void)hipHostFree(st.host);
+        if (st.done) (void)hipEventDestroy(st.done);
+    }
     for (auto& e : c->tev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -588,8 +623,8 @@ RM_EXPORT int rm_write_buffer(rm_ctx* c, int buffer, uint64_t offset, const void
     if (offset > cap || size > cap - offset)
         return fail(c, RM_ERR_TOO_LARGE, "rm_write_buffer: [%llu,+%llu) exceeds the %llu-byte buffer %d",
                     (unsigned long long)offset, (unsigned long long)size, (unsigned long long)cap, buffer);
+    if (buffer == RM_BUF_COMMANDS && size && std::memcmp(dst + offset, data, size) != 0) c->cmd_dirty = true;
     if (size) std::memcpy(dst + offset, data, size);
-    if (buffer == RM_BUF_COMMANDS && size) c->cmd_dirty = true;
     return RM_OK;
 }
 
@@ -613,6 +648,11 @@ RM_EXPORT int rm_set_program(rm_ctx* c, uint32_t cmd_count, const uint32_t* word
         return fail(c, RM_ERR_TOO_LARGE, "rm_set_program: %u words do not fit the %llu-byte command buffer "
                     "(rm_resize_command_buffer lifts the reference's 1024-byte limit)",
                     n_words, (unsigned long long)(c->cmd.size() * 4));
+    // The reference rebuilds and rewrites the command buffer every frame (renderer.rs:224-239); a rewrite that leaves
+    // the buffer as it is keeps the decoded program and its device copy.
+    if (!c->cmd_dirty && c->cmd_status == RM_OK && c->cmd[0] == cmd_count &&
+        (n_words == 0u || std::memcmp(c->cmd.data() + 1, words, (size_t)n_words * 4) == 0))
+        return RM_OK;
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return fail(c, rc, "rm_set_program: %s", rm_status_string(rc));
@@ -655,13 +695,13 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     int rc = check_dims(c, W, H, row0, rows);
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = ensure_program(c);
+    hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
+    rc = ensure_program(c, s);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
     const size_t bytes = (size_t)rows * W * pixel_bytes(c);
-    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, user_stream(c, stream));
-    hipStream_t s = c->stream;
+    if (out_is_device) return launch(c, nullptr, 1, W, H, row0, rows, out_rgba, s);
     rc = ensure_out(c, bytes);
     if (rc != RM_OK) return rc;
     rc = launch(c, nullptr, 1, W, H, row0, rows, c->d_out, s);
@@ -696,7 +736,7 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     if (rows == 0u) return RM_OK;  // more ranks than strips: nothing to do for this one
     if (!out_rgba) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rgba is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = ensure_program(c);
+    rc = ensure_program(c, out_is_device ? user_stream(c, stream) : c->stream);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
@@ -721,11 +761,11 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     int rc = check_dims(c, W, H, 0, H);
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    rc = ensure_program(c);
+    hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
+    rc = ensure_program(c, s);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
-    hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
     if (n_frames > c->d_frames_cap) {
         if (c->d_frames) (void)hipFree(c->d_frames);
         c->d_frames = nullptr;
@@ -733,7 +773,8 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
         HIP_TRY(c, hipMalloc(&c->d_frames, (size_t)n_frames * sizeof(rm_uniforms)));
         c->d_frames_cap = n_frames;
     }
-    HIP_TRY(c, hipMemcpy(c->d_frames, frames, (size_t)n_frames * sizeof(rm_uniforms), hipMemcpyHostToDevice));
+    rc = upload(c, c->d_frames, frames, (size_t)n_frames * sizeof(rm_uniforms), s);
+    if (rc != RM_OK) return rc;
     const size_t bytes = (size_t)n_frames * H * W * pixel_bytes(c);
     if (out_is_device) return launch(c, c->d_frames, n_frames, W, H, 0, H, out_rgba, s);
     rc = ensure_out(c, bytes);

@@ -687,6 +687,69 @@ def test_frames_in_flight_on_context_owned_streams(oracle):
             c.close()
 
 
+def test_program_change_with_a_frame_in_flight(oracle):
+    """wgpu's queue.write_buffer is ordered with the draws of the queue (renderer.rs:230-254): a program written for
+    frame n+1 must not reach frame n, which may still be queued or running when rm_set_program + rm_draw of frame
+    n+1 return.  One context, one stream, six frames back to back alternating between two scenes of the same
+    structure (same specialised kernel, different parameters) and a third of another size, no wait in between; the
+    batch uniforms of rm_draw_batch are uploaded the same way."""
+    import torch
+    W, H = 640, 360          # large enough for a frame to still be in flight when the next program arrives
+    lim = (0.01, 100.0, 96)
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    nodes, root = scenes.g32()
+    progs = [oracle.serialize(nodes, root)]
+    cc, w = progs[0]
+    moved = np.array(w, dtype=np.uint32).copy()
+    fl = moved.view(np.float32)
+    i = 0
+    while i < len(moved):                                # same opcodes, every primitive lifted by 0.4
+        op = int(moved[i])
+        if op in (0, 1):
+            fl[i + 2] += np.float32(0.4)
+            i += 5 if op == 0 else 7
+        else:
+            i += 1
+    progs.append((cc, moved))
+    progs.append(oracle.serialize(*scenes.g8()))
+    refs = [oracle.render(u, lim, c_, w_, W, H, threads=4).tobytes() for c_, w_ in progs]
+    assert len(set(refs)) == 3
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        for mode in (0, 2):
+            r.set_option(_ffi.RM_OPT_SPECIALIZE, mode)
+            order = [0, 1, 0, 2, 1, 0]
+            if mode == 2:                                # compile outside of the pipelined part
+                for k in (0, 2):
+                    r.set_program(*progs[k])
+                    r.draw(W, H)
+            bufs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in order]
+            for b, k in zip(bufs, order):
+                r.set_program(*progs[k])
+                r.draw_device(W, H, b.data_ptr(), stream=_ffi.RM_STREAM_OWN)
+            r.sync_context()
+            for n, (b, k) in enumerate(zip(bufs, order)):
+                assert b.cpu().numpy().tobytes() == refs[k], (mode, n, k)
+        # batches back to back: the second batch's cameras must not reach the first
+        cams, ocams = [], []
+        for ev in ([(1, 35.0, -25.0)], [(1, 80.0, -10.0)], [(1, -60.0, 30.0)], [(1, 10.0, -150.0)]):
+            uu, *_ = oracle.orbit_uniforms((float(W), float(H)), events=ev)
+            ocams.append(uu)
+            cams.append(_ffi.Uniforms.from_buffer_copy(bytes(uu)))
+        r.set_program(*progs[0])
+        out = [torch.zeros((2, H, W, 4), dtype=torch.float32, device="cuda") for _ in range(2)]
+        r.draw_batch_device(cams[:2], W, H, out[0].data_ptr(), stream=_ffi.RM_STREAM_OWN)
+        r.draw_batch_device(cams[2:], W, H, out[1].data_ptr(), stream=_ffi.RM_STREAM_OWN)
+        r.sync_context()
+        for j, cam in enumerate(ocams):
+            ref = oracle.render(cam, lim, cc, w, W, H, threads=4)
+            assert out[j // 2][j % 2].cpu().numpy().tobytes() == ref.tobytes(), j
+    finally:
+        r.close()
+
+
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5_lds", "v5_spec"])
 def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
     """The miss tests inflate every bound by how far SmoothUnion can pull the tree below its leaves (rm_decode.h:
