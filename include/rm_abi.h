@@ -96,8 +96,10 @@ enum rm_status {
     RM_ERR_DEVICE = -9,          /* a HIP call failed; see rm_last_error */
     RM_ERR_NO_DEVICE = -10,      /* no usable GPU */
     RM_ERR_ARG = -11,            /* invalid enum / option value */
-    RM_ERR_TRANSFORM = -12       /* transform push / pop (extension opcodes 200-205) not nested properly, deeper than 8,
+    RM_ERR_TRANSFORM = -12,      /* transform push / pop (extension opcodes 200-205) not nested properly, deeper than 8,
                                     or not around exactly one value */
+    RM_ERR_MATERIAL = -13        /* a Material tag (extension opcode 300) names an index >= 256, or (at draw time) one
+                                    the material table does not have */
 };
 
 /* rm_set_option / rm_get_info keys */
@@ -182,6 +184,15 @@ int rm_set_limits(rm_ctx* ctx, const rm_limits* l);
  * on error the command buffer is left unchanged.  cmd_count = 0 is the `csg_node == None`
  * case (renderer.rs:224-227). */
 int rm_set_program(rm_ctx* ctx, uint32_t cmd_count, const uint32_t* words, uint32_t n_words);
+
+/* Material table (extension; the reference has no materials -- README.md:11 lists them as future work -- and shades
+ * every hit with (0.4, 0.7, 0.1) * diffuse, wgsl:105).  `rgb` = count x 3 floats, count in [1, 256]; entry i is the
+ * albedo of the surfaces tagged by the command [300, i] (a unary postfix tag on the value on top of the stack; a
+ * binary operator keeps the tag of the operand that decides its result, primitives start with tag 0).  The default
+ * table is the single entry (0.4, 0.7, 0.1): programs without tags render exactly as the reference does whatever the
+ * table holds in its other entries.  A draw of a program that names an index >= count fails with RM_ERR_MATERIAL.
+ * Like every buffer write the table is ordered with the draws of the stream. */
+int rm_set_materials(rm_ctx* ctx, uint32_t count, const float* rgb);
 
 /* The reference's TODO (renderer.rs:229): grow the command buffer beyond 1024 bytes.
  * Contents are preserved.  bytes in [1024, 65536], multiple of 4. */

@@ -39,9 +39,12 @@ rmh_node* rmh_smooth_union(const rmh_node* lhs, const rmh_node* rhs, float k);
 rmh_node* rmh_translation(const rmh_node* child, const float offset[3]);
 rmh_node* rmh_rotation(const rmh_node* child, const float quaternion_wijk[4]);
 rmh_node* rmh_scale(const rmh_node* child, float factor);
+/* material tag (extension; README.md:11 "Material system" is future work in the reference): the child, deep-copied,
+ * with its surfaces tagged by entry `index` (< 256) of the table rm_set_materials uploads; serialises to [child..., 300, index] */
+rmh_node* rmh_material(const rmh_node* child, uint32_t index);
 rmh_node* rmh_node_clone(const rmh_node* n);
 void rmh_node_free(rmh_node* n);
-/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced; with extension nodes: g8x, g32s, ext_mix, xform_mix); NULL if unknown. */
+/* Named synthetic scenes (g1, g8, g32, g64, g32_balanced; with extension nodes: g8x, g32s, ext_mix, xform_mix, mat_mix); NULL if unknown. */
 rmh_node* rmh_scene(const char* name);
 
 /* ---- CSGCommandBufferBuilder */

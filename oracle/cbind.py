@@ -64,6 +64,10 @@ def lib():
         L.rmo_render.restype = C.c_int
         L.rmo_render_mt.argtypes = L.rmo_render.argtypes + [u32]
         L.rmo_render_mt.restype = C.c_int
+        L.rmo_render_mt_materials.argtypes = L.rmo_render_mt.argtypes + [f32p, u32]
+        L.rmo_render_mt_materials.restype = C.c_int
+        L.rmo_map_scene_material.argtypes = L.rmo_map_scene.argtypes
+        L.rmo_map_scene_material.restype = u32
         L.rmo_quantize_unorm8.argtypes = [f32p, C.c_uint64, C.c_int, C.POINTER(C.c_uint8)]
         L.rmo_quantize_unorm8.restype = None
         L.rmo_builder_new.restype = C.c_void_p
@@ -140,6 +144,14 @@ def map_scene(cmd_count, words, pos, limits=(0.01, 100.0, 100)):
     return float(lib().rmo_map_scene(cmd_count, _u32p(w), len(np.asarray(words)), C.byref(lim), _f32p(p)))
 
 
+def map_scene_material(cmd_count, words, pos, limits=(0.01, 100.0, 100)):
+    """Extension: the material index carried by map_scene's result at pos."""
+    w = _words(words)
+    lim = Limits(*limits)
+    p = np.asarray(pos, dtype=np.float32)
+    return int(lib().rmo_map_scene_material(cmd_count, _u32p(w), len(np.asarray(words)), C.byref(lim), _f32p(p)))
+
+
 def ray_march(cmd_count, words, o, d, limits=(0.01, 100.0, 100)):
     w = _words(words)
     lim = Limits(*limits)
@@ -180,14 +192,19 @@ def orbit_uniforms(viewport, target=(0, 0, 0), radius=5.0, events=()):
     return u, pos, q, orb
 
 
-def render(u, limits, cmd_count, words, W, H, row0=0, rows=None, threads=1, want_counters=False):
+def render(u, limits, cmd_count, words, W, H, row0=0, rows=None, threads=1, want_counters=False, materials=None):
+    """materials (extension): (n, 3) albedo table for programs with Material commands; None = {(0.4, 0.7, 0.1)}."""
     rows = H - row0 if rows is None else rows
     w = _words(words)
     lim = Limits(*limits)
     out = np.empty((rows, W, 4), dtype=np.float32)
     cnt = Counters()
     nw = len(np.asarray(words))
-    if threads > 1:
+    if materials is not None:
+        m = np.ascontiguousarray(np.asarray(materials, dtype=np.float32).reshape(-1, 3))
+        rc = lib().rmo_render_mt_materials(C.byref(u), C.byref(lim), cmd_count, _u32p(w), nw, W, H, row0, rows,
+                                           _f32p(out), C.byref(cnt), max(1, threads), _f32p(m), len(m))
+    elif threads > 1:
         rc = lib().rmo_render_mt(C.byref(u), C.byref(lim), cmd_count, _u32p(w), nw, W, H, row0, rows,
                                  _f32p(out), C.byref(cnt), threads)
     else:

@@ -63,7 +63,8 @@ enum {
     RMO_ERR_OVERFLOW = -4,   /* value stack deeper than 32 (wgsl:173) */
     RMO_ERR_EMPTY_RESULT = -5,
     RMO_ERR_OPCODE = -6,     /* unknown opcode (only in strict mode) */
-    RMO_ERR_TRANSFORM = -12  /* transform push/pop not nested properly, deeper than 8, or not around exactly one value */
+    RMO_ERR_TRANSFORM = -12, /* transform push/pop not nested properly, deeper than 8, or not around exactly one value */
+    RMO_ERR_MATERIAL = -13   /* a Material command names an index outside the material table (or >= 256) */
 };
 
 /* ---- opcode numbering (csg/builder.rs:1-24) ------------------------------------- */
@@ -90,6 +91,13 @@ enum {
 #define RMO_CMD_SCALE_PUSH 204u       /* s f32 (uniform):     pos = pos / s                                  */
 #define RMO_CMD_SCALE_POP 205u        /*                      value = value * s                              */
 #define RMO_MAX_XFORM_DEPTH 8u
+/* Materials (extension; README.md:11 lists a material system as future work, the reference has none): a unary
+ * postfix tag.  Every value on the stack carries a material index next to its distance; primitives push index 0,
+ * Material(i) sets the index of the value on top, binary operators keep the index of the operand that decides the
+ * result (see map_scene_impl).  The hit colour becomes albedo[index] * diffuse; entry 0 of the default table is the
+ * reference's (0.4, 0.7, 0.1) (wgsl:105), so a program without Material commands renders as before. */
+#define RMO_CMD_MATERIAL 300u     /* index u32 (a plain integer word, not f32 bits) */
+#define RMO_MAX_MATERIALS 256u
 
 /* ---- scalar helpers --------------------------------------------------------------- */
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
@@ -141,6 +149,9 @@ typedef struct {
     const uint32_t* words;
     uint32_t n_words;
     rmo_limits limits;
+    const float* materials; /* extension: n_materials x (r, g, b); NULL = the one-entry default table */
+    uint32_t n_materials;
+    int has_materials;      /* the program contains Material commands */
 } rmo_scene;
 
 /* Validates what the reference leaves as UB (wgsl:177-185 has no bounds checks). */
@@ -169,6 +180,14 @@ RMO_API int rmo_validate_program(uint32_t cmd_count, const uint32_t* words, uint
             /* closes the innermost scope, which must be of its kind and have produced exactly one value */
             if (xsize == 0 || xop[xsize - 1] + 1u != op || depth != xdepth[xsize - 1] + 1u) return RMO_ERR_TRANSFORM;
             xsize--;
+            continue;
+        case RMO_CMD_MATERIAL: /* extension: tags the value on top of the stack */
+            if (ptr + 1 > n_words) return RMO_ERR_TRUNCATED;
+            if (words[ptr] >= RMO_MAX_MATERIALS) return RMO_ERR_MATERIAL;
+            ptr += 1;
+            if (depth < 1) return RMO_ERR_UNDERFLOW;
+            /* inside a transform scope the tagged value must be the scope's own */
+            if (xsize != 0 && depth <= xdepth[xsize - 1]) return RMO_ERR_UNDERFLOW;
             continue;
         case RMO_CMD_SPHERE:
             if (ptr + 4 > n_words) return RMO_ERR_TRUNCATED;
@@ -217,9 +236,15 @@ static v3 rotate_conj(float w, v3 a, v3 p) {
 
 /* map_scene (wgsl:187-203) with eval_cmd* (wgsl:205-252), stream reader (wgsl:152-170)
  * and value stack (wgsl:173-185) inlined. */
-static float map_scene(const rmo_scene* sc, v3 pos) {
+/* mat_out != NULL (extension): also track the material index of every value; *mat_out = the index of the result.
+ * Which operand "decides": Union / SmoothUnion b < a, Subtraction -b > a, Intersection b > a take b's index,
+ * otherwise (ties, NaN) a's -- a was pushed first (wgsl:242-252). */
+static inline __attribute__((always_inline)) float map_scene_impl(const rmo_scene* sc, v3 pos, uint32_t* mat_out) {
+    if (mat_out) *mat_out = 0u;
     if (sc->cmd_count == 0u) return sc->limits.max_dist; /* wgsl:189-191 */
     float stack[32];
+    uint32_t mstack[32];
+    uint32_t vmat = 0u;
     uint32_t size = 0, ptr = 0; /* wgsl:194-195 */
     v3 pstack[RMO_MAX_XFORM_DEPTH];    /* extension: positions saved by transform pushes */
     float sstack[RMO_MAX_XFORM_DEPTH]; /*            and the scale of ScalePush */
@@ -228,7 +253,12 @@ static float map_scene(const rmo_scene* sc, v3 pos) {
     for (uint32_t idx = 0; idx < sc->cmd_count; idx++) {
         uint32_t cmd = w[ptr++]; /* wgsl:198 */
         float val;
+        vmat = 0u;
         switch (cmd) {
+        case RMO_CMD_MATERIAL: /* extension */
+            if (mat_out) mstack[size - 1] = w[ptr];
+            ptr += 1;
+            continue;
         case RMO_CMD_TRANSLATION_PUSH: { /* extension */
             v3 t = { u2f(w[ptr]), u2f(w[ptr + 1]), u2f(w[ptr + 2]) };
             ptr += 3;
@@ -293,6 +323,7 @@ static float map_scene(const rmo_scene* sc, v3 pos) {
             float b = stack[--size];
             float a = stack[--size];
             val = rmo_max(a, b);
+            if (mat_out) vmat = b > a ? mstack[size + 1] : mstack[size];
         } break;
         case RMO_CMD_SMOOTH_UNION: { /* extension: min(a,b) - h*h*k/4, h = max(k-|a-b|,0)/k; k <= 0: plain min */
             float k = u2f(w[ptr]);
@@ -304,32 +335,78 @@ static float map_scene(const rmo_scene* sc, v3 pos) {
                 float h = rmo_max(k - fabsf(a - b), 0.0f) / k;
                 val = val - ((h * h) * k) * 0.25f;
             }
+            if (mat_out) vmat = b < a ? mstack[size + 1] : mstack[size];
         } break;
         case RMO_CMD_UNION: { /* wgsl:242-246 */
             float b = stack[--size];
             float a = stack[--size];
             val = rmo_min(a, b);
+            if (mat_out) vmat = b < a ? mstack[size + 1] : mstack[size];
         } break;
         case RMO_CMD_SUBTRACTION: { /* wgsl:248-252 */
             float b = stack[--size];
             float a = stack[--size];
             val = rmo_max(a, -b);
+            if (mat_out) vmat = -b > a ? mstack[size + 1] : mstack[size];
         } break;
         default: /* wgsl:223-225 */
             val = 0.0f;
             break;
         }
+        if (mat_out) mstack[size] = vmat;
         stack[size++] = val; /* wgsl:199 */
     }
+    if (mat_out) *mat_out = mstack[size - 1];
     return stack[--size]; /* wgsl:202 */
+}
+static float map_scene(const rmo_scene* sc, v3 pos) { return map_scene_impl(sc, pos, NULL); }
+static uint32_t map_scene_material(const rmo_scene* sc, v3 pos) {
+    uint32_t m = 0u;
+    (void)map_scene_impl(sc, pos, &m);
+    return m;
+}
+static int program_has_materials(uint32_t cmd_count, const uint32_t* w, uint32_t* max_index) { /* after validation */
+    uint32_t ptr = 0, found = 0, mx = 0;
+    for (uint32_t i = 0; i < cmd_count; i++) {
+        uint32_t op = w[ptr++];
+        switch (op) {
+        case RMO_CMD_MATERIAL: found = 1; if (w[ptr] > mx) mx = w[ptr]; ptr += 1; break;
+        case RMO_CMD_SPHERE: case RMO_CMD_PLANE: case RMO_CMD_ROTATION_PUSH: ptr += 4; break;
+        case RMO_CMD_BOX: ptr += 6; break;
+        case RMO_CMD_CYLINDER: ptr += 5; break;
+        case RMO_CMD_TRANSLATION_PUSH: ptr += 3; break;
+        case RMO_CMD_SMOOTH_UNION: case RMO_CMD_SCALE_PUSH: ptr += 1; break;
+        default: break;
+        }
+    }
+    if (max_index) *max_index = mx;
+    return (int)found;
+}
+/* Fills the material fields of a validated scene; RMO_ERR_MATERIAL when the program names an index the table lacks. */
+static int scene_set_materials(rmo_scene* sc, const float* rgb, uint32_t n) {
+    uint32_t mx = 0;
+    sc->has_materials = program_has_materials(sc->cmd_count, sc->words, &mx);
+    sc->materials = n ? rgb : NULL;
+    sc->n_materials = n ? n : 1u;
+    if (n > RMO_MAX_MATERIALS || (n && !rgb)) return RMO_ERR_MATERIAL;
+    if (sc->has_materials && mx >= sc->n_materials) return RMO_ERR_MATERIAL;
+    return RMO_OK;
 }
 
 RMO_API float rmo_map_scene(uint32_t cmd_count, const uint32_t* words, uint32_t n_words,
                             const rmo_limits* lim, const float* pos3) {
-    rmo_scene sc = { cmd_count, words, n_words, *lim };
+    rmo_scene sc = { cmd_count, words, n_words, *lim, NULL, 1u, 0 };
     if (rmo_validate_program(cmd_count, words, n_words, 0, NULL) != RMO_OK) return NAN;
     v3 p = { pos3[0], pos3[1], pos3[2] };
     return map_scene(&sc, p);
+}
+/* extension: the material index map_scene's result carries at pos (0xFFFFFFFF for an invalid program) */
+RMO_API uint32_t rmo_map_scene_material(uint32_t cmd_count, const uint32_t* words, uint32_t n_words,
+                                        const rmo_limits* lim, const float* pos3) {
+    rmo_scene sc = { cmd_count, words, n_words, *lim, NULL, 1u, 0 };
+    if (rmo_validate_program(cmd_count, words, n_words, 0, NULL) != RMO_OK) return 0xFFFFFFFFu;
+    v3 p = { pos3[0], pos3[1], pos3[2] };
+    return map_scene_material(&sc, p);
 }
 
 /* calculate_normal (wgsl:135-144): tetrahedron taps, eps = 0.0001, k = (1,-1). */
@@ -364,7 +441,14 @@ static v3 ray_march(const rmo_scene* sc, v3 o, v3 d, rmo_counters* cnt) {
             v3 tl = { pos.x - 2.0f, pos.y - (-5.0f), pos.z - 3.0f }; /* pos - light_position */
             v3 dl = normalize3(tl);
             float diffuse = rmo_max(0.02f, dot3(n, dl));
-            v3 c = { 0.4f * diffuse, 0.7f * diffuse, 0.1f * diffuse };
+            v3 c = { 0.4f * diffuse, 0.7f * diffuse, 0.1f * diffuse }; /* wgsl:105 */
+            if (sc->has_materials) { /* extension: albedo of the material the surface carries at pos */
+                uint32_t m = map_scene_material(sc, pos);
+                if (sc->materials) {
+                    const float* al = sc->materials + 3u * m;
+                    c.x = al[0] * diffuse; c.y = al[1] * diffuse; c.z = al[2] * diffuse;
+                }
+            }
             if (cnt) cnt->hits++;
             return c;
         }
@@ -392,7 +476,7 @@ static v3 ray_march(const rmo_scene* sc, v3 o, v3 d, rmo_counters* cnt) {
 
 RMO_API void rmo_ray_march(uint32_t cmd_count, const uint32_t* words, uint32_t n_words,
                            const rmo_limits* lim, const float* o3, const float* d3, float* rgb3) {
-    rmo_scene sc = { cmd_count, words, n_words, *lim };
+    rmo_scene sc = { cmd_count, words, n_words, *lim, NULL, 1u, 0 };
     v3 o = { o3[0], o3[1], o3[2] }, d = { d3[0], d3[1], d3[2] };
     v3 c = { NAN, NAN, NAN };
     if (rmo_validate_program(cmd_count, words, n_words, 0, NULL) == RMO_OK)
@@ -451,7 +535,9 @@ RMO_API int rmo_render(const rmo_uniforms* u, const rmo_limits* lim, uint32_t cm
     if (!u || !lim || !out) return RMO_ERR_NULL;
     int rc = rmo_validate_program(cmd_count, words, n_words, 0, NULL);
     if (rc != RMO_OK) return rc;
-    rmo_scene sc = { cmd_count, words, n_words, *lim };
+    rmo_scene sc = { cmd_count, words, n_words, *lim, NULL, 1u, 0 };
+    rc = scene_set_materials(&sc, NULL, 0);
+    if (rc != RMO_OK) return rc;
     rmo_counters c;
     memset(&c, 0, sizeof c);
     for (uint32_t r = 0; r < rows; r++)
@@ -485,16 +571,19 @@ static void* mt_worker(void* arg) {
     return NULL;
 }
 
-RMO_API int rmo_render_mt(const rmo_uniforms* u, const rmo_limits* lim, uint32_t cmd_count,
-                          const uint32_t* words, uint32_t n_words, uint32_t W, uint32_t H,
-                          uint32_t row0, uint32_t rows, float* out, rmo_counters* counters,
-                          uint32_t n_threads) {
+/* materials: n_materials x (r, g, b) floats, or n_materials = 0 for the default table {(0.4, 0.7, 0.1)} */
+RMO_API int rmo_render_mt_materials(const rmo_uniforms* u, const rmo_limits* lim, uint32_t cmd_count,
+                                    const uint32_t* words, uint32_t n_words, uint32_t W, uint32_t H,
+                                    uint32_t row0, uint32_t rows, float* out, rmo_counters* counters,
+                                    uint32_t n_threads, const float* materials, uint32_t n_materials) {
     if (!u || !lim || !out) return RMO_ERR_NULL;
     int rc = rmo_validate_program(cmd_count, words, n_words, 0, NULL);
     if (rc != RMO_OK) return rc;
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
-    rmo_scene sc = { cmd_count, words, n_words, *lim };
+    rmo_scene sc = { cmd_count, words, n_words, *lim, NULL, 1u, 0 };
+    rc = scene_set_materials(&sc, materials, n_materials);
+    if (rc != RMO_OK) return rc;
     pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
     uint32_t next_row = 0;
     mt_job* jobs = (mt_job*)calloc(n_threads, sizeof(mt_job));
@@ -519,6 +608,12 @@ RMO_API int rmo_render_mt(const rmo_uniforms* u, const rmo_limits* lim, uint32_t
     free(th);
     if (counters) *counters = tot;
     return RMO_OK;
+}
+RMO_API int rmo_render_mt(const rmo_uniforms* u, const rmo_limits* lim, uint32_t cmd_count,
+                          const uint32_t* words, uint32_t n_words, uint32_t W, uint32_t H,
+                          uint32_t row0, uint32_t rows, float* out, rmo_counters* counters,
+                          uint32_t n_threads) {
+    return rmo_render_mt_materials(u, lim, cmd_count, words, n_words, W, H, row0, rows, out, counters, n_threads, NULL, 0);
 }
 
 /* ---- wire format: CSGCommandBufferBuilder (csg/builder.rs:26-62) --------------------- */
@@ -593,6 +688,11 @@ RMO_API void rmo_build_commands(const rmo_node* nodes, int32_t root, rmo_builder
             rmo_builder_push_param_float(b, n->p[k]);
         rmo_build_commands(nodes, n->lhs, b);
         rmo_builder_push_command(b, n->kind + 1u);
+        break;
+    case RMO_CMD_MATERIAL: /* extension: the child (lhs), then the tag; p[0] = index as a float-valued integer */
+        rmo_build_commands(nodes, n->lhs, b);
+        rmo_builder_push_command(b, RMO_CMD_MATERIAL);
+        bpush(b, (uint32_t)n->p[0]);
         break;
     case RMO_CMD_SMOOTH_UNION: /* extension: lhs, rhs, operator, k */
         rmo_build_commands(nodes, n->lhs, b);

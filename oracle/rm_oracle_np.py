@@ -16,6 +16,7 @@ F = np.float32
 CMD_SPHERE, CMD_BOX, CMD_UNION, CMD_SUBTRACTION = 0, 1, 100, 101
 CMD_TRANSLATION_PUSH, CMD_TRANSLATION_POP, CMD_ROTATION_PUSH, CMD_ROTATION_POP, CMD_SCALE_PUSH, CMD_SCALE_POP = range(200, 206)
 CMD_PLANE, CMD_CYLINDER, CMD_INTERSECTION, CMD_SMOOTH_UNION = 2, 10, 102, 110   # extensions (not in the reference)
+CMD_MATERIAL = 300          # extension: tags the value on top of the stack with a material index (rm_oracle.c)
 
 
 def _f(x):
@@ -62,12 +63,15 @@ def _wf(words, i):
     return words[i:i + 1].view(F)[0]
 
 
-def map_scene(cmd_count, words, max_dist, px, py, pz):
-    """wgsl:187-203 for arrays of positions."""
+def map_scene(cmd_count, words, max_dist, px, py, pz, want_material=False):
+    """wgsl:187-203 for arrays of positions.  want_material (extension): returns (distance, material index) -- every
+    value carries the index of the operand that decided it; primitives carry 0, Material(i) overwrites the top."""
     if cmd_count == 0:
-        return np.full(px.shape, F(max_dist), dtype=F)
+        d0 = np.full(px.shape, F(max_dist), dtype=F)
+        return (d0, np.zeros(px.shape, dtype=np.uint32)) if want_material else d0
     words = decode_words(words)
     stack = []
+    mats = []    # parallel to stack: uint32 arrays
     saved = []   # extension: (position, scale) saved by the transform pushes (opcodes 200-205)
     ptr = 0
     for _ in range(cmd_count):
@@ -91,11 +95,15 @@ def map_scene(cmd_count, words, max_dist, px, py, pz):
             with np.errstate(divide="ignore", invalid="ignore"):
                 px, py, pz = px / sf, py / sf, pz / sf
             continue
+        if op == CMD_MATERIAL:
+            mats[-1] = np.full(px.shape, int(words[ptr]), dtype=np.uint32); ptr += 1
+            continue
         if op in (CMD_TRANSLATION_POP, CMD_ROTATION_POP, CMD_SCALE_POP):
             px, py, pz, sf = saved.pop()
             if op == CMD_SCALE_POP:
                 stack[-1] = (stack[-1] * sf).astype(F)
             continue
+        mat = np.zeros(px.shape, dtype=np.uint32)
         if op == CMD_SPHERE:
             cx, cy, cz, r = (_wf(words, ptr + k) for k in range(4)); ptr += 4
             dx, dy, dz = px - cx, py - cy, pz - cz
@@ -118,26 +126,35 @@ def map_scene(cmd_count, words, max_dist, px, py, pz):
             mx, my = fmax(qx, F(0)), fmax(qy, F(0))
             val = fmin(fmax(qx, qy), F(0)) + np.sqrt(mx * mx + my * my)
         elif op == CMD_INTERSECTION:
-            b = stack.pop(); a = stack.pop()
+            b = stack.pop(); a = stack.pop(); mb = mats.pop(); ma = mats.pop()
             val = fmax(a, b)
+            with np.errstate(invalid="ignore"):
+                mat = np.where(b > a, mb, ma)
         elif op == CMD_SMOOTH_UNION:
             k = _wf(words, ptr); ptr += 1
-            b = stack.pop(); a = stack.pop()
+            b = stack.pop(); a = stack.pop(); mb = mats.pop(); ma = mats.pop()
+            with np.errstate(invalid="ignore"):
+                mat = np.where(b < a, mb, ma)
             val = fmin(a, b)
             if k > 0:
                 with np.errstate(invalid="ignore"):
                     h = fmax(k - np.abs(a - b), F(0)) / k
                 val = val - ((h * h) * k) * F(0.25)
         elif op == CMD_UNION:
-            b = stack.pop(); a = stack.pop()
+            b = stack.pop(); a = stack.pop(); mb = mats.pop(); ma = mats.pop()
             val = fmin(a, b)
+            with np.errstate(invalid="ignore"):
+                mat = np.where(b < a, mb, ma)
         elif op == CMD_SUBTRACTION:
-            b = stack.pop(); a = stack.pop()
+            b = stack.pop(); a = stack.pop(); mb = mats.pop(); ma = mats.pop()
             val = fmax(a, -b)
+            with np.errstate(invalid="ignore"):
+                mat = np.where(-b > a, mb, ma)
         else:
             val = np.zeros(px.shape, dtype=F)
         stack.append(val.astype(F))
-    return stack.pop()
+        mats.append(mat.astype(np.uint32))
+    return (stack.pop(), mats.pop()) if want_material else stack.pop()
 
 
 def _normalize3(x, y, z):
@@ -146,8 +163,8 @@ def _normalize3(x, y, z):
         return x / l, y / l, z / l
 
 
-def ray_march(cmd_count, words, limits, ox, oy, oz, dx, dy, dz):
-    """wgsl:87-131 for arrays of rays.  Returns rgb arrays (linear)."""
+def ray_march(cmd_count, words, limits, ox, oy, oz, dx, dy, dz, materials=None):
+    """wgsl:87-131 for arrays of rays.  Returns rgb arrays (linear).  materials (extension): (n, 3) albedo table."""
     min_dist, max_dist, max_iter = F(limits[0]), F(limits[1]), int(limits[2])
     n = dx.shape[0]
     col = np.zeros((3, n), dtype=F)
@@ -189,9 +206,15 @@ def ray_march(cmd_count, words, limits, ox, oy, oz, dx, dy, dz):
         nx, ny, nz = _normalize3(*acc)
         lx, ly, lz = _normalize3(hx - F(2.0), hy - F(-5.0), hz - F(3.0))
         diffuse = fmax(F(0.02), (nx * lx + ny * ly) + nz * lz)
-        col[0, hi] = F(0.4) * diffuse
-        col[1, hi] = F(0.7) * diffuse
-        col[2, hi] = F(0.1) * diffuse
+        if materials is None:
+            col[0, hi] = F(0.4) * diffuse
+            col[1, hi] = F(0.7) * diffuse
+            col[2, hi] = F(0.1) * diffuse
+        else:
+            table = np.asarray(materials, dtype=F).reshape(-1, 3)
+            _, m = map_scene(cmd_count, words, max_dist, hx, hy, hz, want_material=True)
+            for ch in range(3):
+                col[ch, hi] = table[m, ch] * diffuse
     miss = np.nonzero(~is_hit)[0]
     if miss.size:
         with np.errstate(invalid="ignore", divide="ignore", over="ignore"):
@@ -217,7 +240,7 @@ def _matvec(m, x, y, z, w):
     return tuple(((m[0 + r] * x + m[4 + r] * y) + m[8 + r] * z) + m[12 + r] * w for r in range(4))
 
 
-def render(uniforms, limits, cmd_count, words, W, H, row0=0, rows=None):
+def render(uniforms, limits, cmd_count, words, W, H, row0=0, rows=None, materials=None):
     """fs_main (wgsl:36-76) over rows [row0,row0+rows) -> (rows, W, 4) float32."""
     rows = H - row0 if rows is None else rows
     ve = _f(uniforms["viewport_extent"])
@@ -247,7 +270,7 @@ def render(uniforms, limits, cmd_count, words, W, H, row0=0, rows=None):
             ln = np.sqrt(((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) + d[3] * d[3])
             rd = [d[k] / ln for k in range(3)]
             o = [np.full(n, ro[k], dtype=F) for k in range(3)]
-            c = ray_march(cmd_count, words, limits, o[0], o[1], o[2], rd[0], rd[1], rd[2])
+            c = ray_march(cmd_count, words, limits, o[0], o[1], o[2], rd[0], rd[1], rd[2], materials)
             total = total + np.sqrt(c)
     out = np.empty((rows * W, 4), dtype=F)
     out[:, 0] = total[0] / F(16)

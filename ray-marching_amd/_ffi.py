@@ -28,7 +28,7 @@ class Limits(C.Structure):
 # status codes (include/rm_abi.h enum rm_status)
 RM_OK, RM_ERR_NULL, RM_ERR_TRUNCATED, RM_ERR_STACK_UNDERFLOW, RM_ERR_STACK_OVERFLOW = 0, -1, -2, -3, -4
 RM_ERR_EMPTY_RESULT, RM_ERR_OPCODE, RM_ERR_TOO_LARGE, RM_ERR_RANGE, RM_ERR_DEVICE = -5, -6, -7, -8, -9
-RM_ERR_NO_DEVICE, RM_ERR_ARG, RM_ERR_TRANSFORM = -10, -11, -12
+RM_ERR_NO_DEVICE, RM_ERR_ARG, RM_ERR_TRANSFORM, RM_ERR_MATERIAL = -10, -11, -12, -13
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
 RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
 RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE, RM_OPT_PRUNE = 5, 6, 7, 8, 9
@@ -92,6 +92,7 @@ def hip_lib():
         L.rm_set_uniforms.argtypes = [vp, C.POINTER(Uniforms)]
         L.rm_set_limits.argtypes = [vp, C.POINTER(Limits)]
         L.rm_set_program.argtypes = [vp, u32, C.POINTER(u32), u32]
+        L.rm_set_materials.argtypes = [vp, u32, C.POINTER(C.c_float)]
         L.rm_resize_command_buffer.argtypes = [vp, u64]
         L.rm_validate.argtypes = [vp]
         L.rm_validate_program.argtypes = [u32, C.POINTER(u32), u32, C.POINTER(u32)]
@@ -126,7 +127,7 @@ def hip_lib():
         L.rm_status_string.restype = C.c_char_p
         for name in ("rm_create", "rm_write_buffer", "rm_set_uniforms", "rm_set_limits", "rm_set_program",
                      "rm_resize_command_buffer", "rm_validate", "rm_draw", "rm_draw_batch", "rm_sync",
-                     "rm_set_option", "rm_get_info", "rm_measure_write_bandwidth"):
+                     "rm_set_option", "rm_get_info", "rm_measure_write_bandwidth", "rm_set_materials"):
             getattr(L, name).restype = C.c_int
         _hip = L
     return _hip
@@ -171,11 +172,12 @@ def host_lib():
         L.rmh_translation.argtypes = [vp, f32p]
         L.rmh_rotation.argtypes = [vp, f32p]
         L.rmh_scale.argtypes = [vp, C.c_float]
+        L.rmh_material.argtypes = [vp, u32]
         L.rmh_node_clone.argtypes = [vp]
         L.rmh_scene.argtypes = [C.c_char_p]
         for n in ("rmh_sphere", "rmh_box", "rmh_union", "rmh_subtraction", "rmh_node_clone", "rmh_scene",
                   "rmh_builder_new", "rmh_plane", "rmh_cylinder", "rmh_intersection", "rmh_smooth_union",
-                  "rmh_translation", "rmh_rotation", "rmh_scale"):
+                  "rmh_translation", "rmh_rotation", "rmh_scale", "rmh_material"):
             getattr(L, n).restype = vp
         L.rmh_node_free.argtypes = [vp]
         L.rmh_node_free.restype = None

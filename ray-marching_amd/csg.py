@@ -21,6 +21,7 @@ class CSGCommandType(enum.IntEnum):  # builder.rs:3-24
     Intersection = 102
     SmoothUnion = 110
     TranslationPush, TranslationPop, RotationPush, RotationPop, ScalePush, ScalePop = 200, 201, 202, 203, 204, 205
+    Material = 300
 
 
 def _f3(v):
@@ -130,6 +131,12 @@ def Rotation(child, quaternion=(1.0, 0.0, 0.0, 0.0)):
 def Scale(child, factor=1.0):
     """The child scaled uniformly by `factor` > 0 (csg/mod.rs:43; opcodes 204 / 205)."""
     return CSGNode(_ffi.host_lib().rmh_scale(child._h, float(factor)))
+
+
+def Material(child, index=0):
+    """The child with its surfaces tagged by entry `index` of the material table (RayMarchingResources.set_materials).
+    The reference has no materials (README.md:11 lists them as future work); opcode 300, one u32 parameter."""
+    return CSGNode(_ffi.host_lib().rmh_material(child._h, int(index)))
 
 
 def scene(name):

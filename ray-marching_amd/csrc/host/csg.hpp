@@ -33,6 +33,8 @@ enum class CSGCommandType : uint32_t {  // builder.rs:3-24
     RotationPop = 203,
     ScalePush = 204,
     ScalePop = 205,
+    // material tag (the reference lists a material system as future work, README.md:11): unary postfix, one u32 index
+    Material = 300,
 };
 
 struct CSGCommandBufferBuilder {  // builder.rs:26-62
@@ -50,6 +52,10 @@ struct CSGCommandBufferBuilder {  // builder.rs:26-62
     }
     CSGCommandBufferBuilder& push_param_float(float value) {
         buffer.push_back(to_bits(value));
+        return *this;
+    }
+    CSGCommandBufferBuilder& push_param_u32(uint32_t value) {  // extension: integer parameters (Material index)
+        buffer.push_back(value);
         return *this;
     }
     static uint32_t to_bits(float f) {
@@ -148,9 +154,15 @@ struct Scale {  // the child scaled uniformly by `factor` (> 0)
     void build_commands(CSGCommandBufferBuilder& builder) const;
 };
 
+struct Material {  // the child with every surface tagged by material `index` (rm_set_materials)
+    NodeBox child;
+    uint32_t index = 0;
+    void build_commands(CSGCommandBufferBuilder& builder) const;
+};
+
 class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands) + the extension node types
   public:
-    using Variant = std::variant<Sphere, Box, Union, Subtraction, Plane, Cylinder, Intersection, SmoothUnion, Translation, Rotation, Scale>;
+    using Variant = std::variant<Sphere, Box, Union, Subtraction, Plane, Cylinder, Intersection, SmoothUnion, Translation, Rotation, Scale, Material>;
     CSGNode(Sphere s) : v_(std::move(s)) {}
     CSGNode(Box b) : v_(std::move(b)) {}
     CSGNode(Union u) : v_(std::move(u)) {}
@@ -162,6 +174,7 @@ class CSGNode {  // csg/mod.rs:28-45 (enum_dispatch over BuildCommands) + the ex
     CSGNode(Translation t) : v_(std::move(t)) {}
     CSGNode(Rotation r) : v_(std::move(r)) {}
     CSGNode(Scale s) : v_(std::move(s)) {}
+    CSGNode(Material m) : v_(std::move(m)) {}
     void build_commands(CSGCommandBufferBuilder& builder) const {
         std::visit([&](const auto& n) { n.build_commands(builder); }, v_);
     }
@@ -218,6 +231,11 @@ inline void Scale::build_commands(CSGCommandBufferBuilder& builder) const {
     child->build_commands(builder);
     builder.push_command(CSGCommandType::ScalePop);
 }
+inline void Material::build_commands(CSGCommandBufferBuilder& builder) const {
+    child->build_commands(builder);
+    builder.push_command(CSGCommandType::Material).push_param_u32(index);
+}
+inline CSGNode make_material(CSGNode child, uint32_t index) { return CSGNode(Material{NodeBox(std::move(child)), index}); }
 inline CSGNode make_translation(CSGNode child, std::array<float, 3> offset) { return CSGNode(Translation{NodeBox(std::move(child)), offset}); }
 inline CSGNode make_rotation(CSGNode child, std::array<float, 4> q) { return CSGNode(Rotation{NodeBox(std::move(child)), q}); }
 inline CSGNode make_scale(CSGNode child, float factor) { return CSGNode(Scale{NodeBox(std::move(child)), factor}); }

@@ -113,7 +113,25 @@ inline CSGNode xform_mix() {  // space transformations, nested, around primitive
     return csg::make_union(csg::make_union(csg::make_union(std::move(a), std::move(b)), std::move(c)), std::move(d));
 }
 
+inline CSGNode mat_mix() {  // material tags on leaves, on sub-trees, inside transform scopes, under every operator
+    using csg::make_material;
+    const float h = 0.70710678f;
+    CSGNode body = csg::make_union(make_material(CSGNode(csg::Sphere{{0, 0, 0}, 1.0f}), 1), make_material(CSGNode(csg::Box{{0, 0, 0}, {0.8f, 0.8f, 0.8f}}), 2));
+    CSGNode carved = csg::make_subtraction(std::move(body), make_material(CSGNode(csg::Sphere{{0.9f, 0.5f, 0.6f}, 0.6f}), 3));
+    CSGNode slab(csg::Box{{0, -1.2f, 0}, {1.5f, 0.1f, 1.5f}});
+    CSGNode arm = csg::make_translation(csg::make_rotation(make_material(CSGNode(csg::Cylinder{{0, 0, 0}, 0.25f, 0.9f}), 5), {h, 0, 0, h}), {-1.3f, 0.4f, 0.3f});
+    CSGNode blob = make_material(csg::make_smooth_union(make_material(CSGNode(csg::Sphere{{1.3f, 0.2f, -0.6f}, 0.45f}), 1),
+                                                        CSGNode(csg::Sphere{{1.7f, 0.5f, -0.3f}, 0.35f}), 0.3f), 4);
+    CSGNode cut = csg::make_intersection(make_material(CSGNode(csg::Box{{-0.2f, 1.3f, -0.9f}, {0.5f, 0.5f, 0.5f}}), 2),
+                                         make_material(CSGNode(csg::Sphere{{-0.2f, 1.3f, -0.9f}, 0.62f}), 3));
+    CSGNode twin = csg::make_scale(csg::make_smooth_union(make_material(CSGNode(csg::Sphere{{-2.0f, -0.6f, 1.6f}, 0.5f}), 3),
+                                                          make_material(CSGNode(csg::Box{{-1.2f, -0.6f, 1.6f}, {0.4f, 0.4f, 0.4f}}), 5), 0.4f), 0.8f);
+    return csg::make_union(csg::make_union(csg::make_union(csg::make_union(csg::make_union(std::move(carved), std::move(slab)), std::move(arm)),
+                                                           std::move(blob)), std::move(cut)), std::move(twin));
+}
+
 inline std::optional<CSGNode> by_name(const std::string& name) {
+    if (name == "mat_mix") return mat_mix();
     if (name == "xform_mix") return xform_mix();
     if (name == "g8x") return g8x();
     if (name == "g32s") return g32s();

@@ -54,6 +54,12 @@ struct rm_ctx {
     size_t d_prog_cap = 0;
     float4* d_bounds = nullptr;  // world-space bounding spheres of a program with transforms (RmDecoded::bounds)
     size_t d_bounds_cap = 0;
+    // materials (extension): the tagged decoding of the program and the albedo table
+    RmRecord* d_mprog = nullptr;
+    size_t d_mprog_cap = 0;
+    std::vector<float4> materials{make_float4(0.4f, 0.7f, 0.1f, 0.0f)};  // wgsl:105
+    float4* d_materials = nullptr;  // RM_MAX_MATERIALS entries
+    bool materials_dirty = true;
     // scratch for host-destination draws and batch uniforms
     float* d_out = nullptr;
     size_t d_out_bytes = 0;
@@ -194,9 +200,41 @@ int ensure_program(rm_ctx* c, hipStream_t s) {
             return urc;
         }
     }
+    if (!d.mrec.empty()) {
+        if (d.mrec.size() > c->d_mprog_cap) {
+            if (c->d_mprog) (void)hipFree(c->d_mprog);
+            c->d_mprog = nullptr;
+            c->d_mprog_cap = 0;
+            const size_t cap = std::max<size_t>(64, d.mrec.size() * 2);
+            hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->d_mprog), cap * sizeof(RmRecord));
+            if (e != hipSuccess) {
+                c->cmd_dirty = true;
+                return fail(c, RM_ERR_DEVICE, "hipMalloc(material program) failed: %s", hipGetErrorString(e));
+            }
+            c->d_mprog_cap = cap;
+        }
+        if (int urc = upload(c, c->d_mprog, d.mrec.data(), d.mrec.size() * sizeof(RmRecord), s)) {
+            c->cmd_dirty = true;
+            return urc;
+        }
+    }
     c->decoded = std::move(d);
     c->prog_gen++;
     c->cmd_status = RM_OK;
+    return RM_OK;
+}
+
+// The material table of a tagged program, on the stream of the draw that needs it.
+int ensure_materials(rm_ctx* c, hipStream_t s) {
+    if (!c->decoded.has_materials) return RM_OK;
+    if (c->decoded.max_material >= c->materials.size())
+        return fail(c, RM_ERR_MATERIAL, "the program tags a surface with material %u, the material table has %zu entries "
+                    "(rm_set_materials)", c->decoded.max_material, c->materials.size());
+    if (!c->d_materials) HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->d_materials), RM_MAX_MATERIALS * sizeof(float4)));
+    if (c->materials_dirty) {
+        if (int rc = upload(c, c->d_materials, c->materials.data(), c->materials.size() * sizeof(float4), s)) return rc;
+        c->materials_dirty = false;
+    }
     return RM_OK;
 }
 
@@ -207,7 +245,7 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
     if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
-        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, c->prune && c->decoded.prunable);
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, c->prune && c->decoded.prunable, c->decoded.has_materials);
         c->spec_gen = c->prog_gen;
         c->spec_wpt = wpt;
     }
@@ -318,9 +356,12 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // structure-specialised kernel (values live in registers: no LDS spill stack)
     hipFunction_t spec_fn = lds ? specialised_kernel(c, WPT) : nullptr;
     if (spec_fn) L.spill_depth = 0u;
+    // the material evaluation of a tagged program borrows the spill area: (distance, index) pairs + saved positions
+    if (L.n_mrec != 0u) L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
     const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
-                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms);
+                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms) +
+                         (L.n_mrec != 0u ? 1024u : 0u);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
     if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
@@ -376,8 +417,9 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
     int wpt = c->waves_per_tile;
-    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
-    while (wpt > 1 && fixed + (size_t)wpt * (rmk::V5_WAVE_DWORDS * 4u + (size_t)L.spill_depth * 256u) > 48u * 1024u)
+    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + 16u + (L.n_mrec != 0u ? 1024u : 0u);
+    const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
+    while (wpt > 1 && fixed + (size_t)wpt * (rmk::V5_WAVE_DWORDS * 4u + depth * 256u) > 48u * 1024u)
         wpt /= 2;
     switch (wpt) {
     case 1: return launch_v5_w<1>(c, L, lds, n_frames, s);
@@ -419,6 +461,10 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.value_spill_depth = c->decoded.spill_depth;
     L.spill_depth = c->decoded.spill_depth + 3u * c->decoded.xform_depth;  // saved positions follow the value stack
     L.bounds = c->decoded.has_xforms ? c->d_bounds : nullptr;
+    L.mprog = c->d_mprog;
+    L.n_mrec = (uint32_t)c->decoded.mrec.size();
+    L.mat_value_depth = c->decoded.mat_spill_depth;
+    L.materials = c->d_materials;
     L.n_cull = 0;
     L.flags = 0;
     L.n_cone = c->decoded.n_sphere;
@@ -595,6 +641,8 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->d_measured) (void)hipFree(c->d_measured);
     if (c->d_bounds) (void)hipFree(c->d_bounds);
+    if (c->d_mprog) (void)hipFree(c->d_mprog);
+    if (c->d_materials) (void)hipFree(c->d_materials);
     for (auto& st : c->staging) {
         if (st.host) (void)hipHostFree(st.host);
         if (st.done) (void)hipEventDestroy(st.done);
@@ -662,6 +710,17 @@ RM_EXPORT int rm_set_program(rm_ctx* c, uint32_t cmd_count, const uint32_t* word
     return RM_OK;
 }
 
+RM_EXPORT int rm_set_materials(rm_ctx* c, uint32_t count, const float* rgb) {
+    if (!c) return RM_ERR_NULL;
+    if (!rgb) return fail(c, RM_ERR_NULL, "rm_set_materials: rgb is NULL");
+    if (count < 1u || count > RM_MAX_MATERIALS)
+        return fail(c, RM_ERR_MATERIAL, "rm_set_materials: %u entries, the table holds 1 to %u", count, (unsigned)RM_MAX_MATERIALS);
+    c->materials.resize(count);
+    for (uint32_t i = 0; i < count; i++) c->materials[i] = make_float4(rgb[3u * i], rgb[3u * i + 1u], rgb[3u * i + 2u], 0.0f);
+    c->materials_dirty = true;
+    return RM_OK;
+}
+
 RM_EXPORT int rm_resize_command_buffer(rm_ctx* c, uint64_t bytes) {
     if (!c) return RM_ERR_NULL;
     if (bytes < kRefCmdBufferBytes || bytes > kMaxCmdBufferBytes || (bytes & 3u))
@@ -697,6 +756,7 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
     rc = ensure_program(c, s);
+    if (rc == RM_OK) rc = ensure_materials(c, s);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
@@ -737,6 +797,7 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     if (!out_rgba) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rgba is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
     rc = ensure_program(c, out_is_device ? user_stream(c, stream) : c->stream);
+    if (rc == RM_OK) rc = ensure_materials(c, out_is_device ? user_stream(c, stream) : c->stream);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
@@ -763,6 +824,7 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
     rc = ensure_program(c, s);
+    if (rc == RM_OK) rc = ensure_materials(c, s);
     if (rc != RM_OK) return rc;
     rc = check_limits(c);
     if (rc != RM_OK) return rc;
@@ -960,7 +1022,7 @@ int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int 
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return rc;
-    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, prune && d.prunable, src)) return RM_ERR_ARG;
+    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, prune && d.prunable, d.has_materials, src)) return RM_ERR_ARG;
     return RM_OK;
 }
 void copy_out(const std::string& s, char* buf, size_t cap) {
@@ -1023,6 +1085,7 @@ RM_EXPORT const char* rm_status_string(int status) {
     case RM_ERR_NO_DEVICE: return "no GPU available";
     case RM_ERR_ARG: return "invalid argument";
     case RM_ERR_TRANSFORM: return "transform push/pop commands are not properly nested around one value";
+    case RM_ERR_MATERIAL: return "material index outside the material table";
     default: return "unknown status";
     }
 }

@@ -39,6 +39,14 @@ struct RmDecoded {
     uint32_t xform_depth = 0;
     bool has_xforms = false, cull_veto = false;
     std::vector<float> bounds;  // 4 floats per cone slot; empty unless has_xforms
+    // Materials (extension): `rec` never contains the tags (the march does not depend on them, so a tagged scene
+    // keeps its untagged structure, fusion and specialised kernel); `mrec` is the program decoded with the tags in
+    // place, for the one evaluation per hit that asks which material the surface carries.
+    bool has_materials = false;
+    uint32_t max_material = 0;       // largest index a tag names
+    std::vector<RmRecord> mrec;
+    uint32_t mat_spill_depth = 0;    // value-stack spill slots of mrec (each holds a distance and an index)
+    uint32_t mat_xform_depth = 0;
 };
 
 // One open transform scope during decoding.
@@ -50,8 +58,8 @@ struct RmXformScope {
 
 // Returns RM_OK or a negative rm_status.  `cap_words` is the number of u32 words that
 // exist after the cmd_count word (255 for the reference's 1024-byte buffer).
-static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, uint32_t cap_words,
-                                    RmDecoded* out) {
+static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint32_t cap_words, bool keep_materials,
+                                 RmDecoded* out) {
     RmDecoded d;
     if (cmd_count && cap_words && !words) return RM_ERR_NULL;
     // Every command is at least one word, so at most cap_words records can ever be produced.
@@ -63,7 +71,7 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             const uint32_t op = words[q++];
             if (op >= RM_CMD_TRANSLATION_PUSH && op <= RM_CMD_SCALE_POP) { d.has_xforms = true; break; }
             q += op == RM_CMD_SPHERE || op == RM_CMD_PLANE ? 4u : op == RM_CMD_BOX ? 6u : op == RM_CMD_CYLINDER ? 5u
-               : op == RM_CMD_SMOOTH_UNION ? 1u : 0u;
+               : op == RM_CMD_SMOOTH_UNION || op == RM_CMD_MATERIAL ? 1u : 0u;
         }
     }
     std::vector<RmXformScope> scopes;
@@ -118,6 +126,19 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
             std::memcpy(&r.p[6], &level, 4);
             scopes.pop_back();
             r.op = RM_OP(RM_KIND_XFORM, op == RM_CMD_TRANSLATION_POP ? RM_XF_T_POP : op == RM_CMD_ROTATION_POP ? RM_XF_R_POP : RM_XF_S_POP, 0);
+            d.rec.push_back(r);
+            continue;
+        }
+        if (op == RM_CMD_MATERIAL && keep_materials) {  // tags the value on top of the stack (inside a scope: the scope's own)
+            if (ptr + 1 > cap_words) return RM_ERR_TRUNCATED;
+            const uint32_t index = words[ptr++];
+            if (index >= RM_MAX_MATERIALS) return RM_ERR_MATERIAL;
+            if (depth < 1 || (!scopes.empty() && depth <= scopes.back().depth)) return RM_ERR_STACK_UNDERFLOW;
+            std::memcpy(&r.p[0], &index, 4);
+            r.op = RM_OP(RM_KIND_MATERIAL, 0, 0);
+            d.has_materials = true;
+            d.has_extensions = true;
+            if (index > d.max_material) d.max_material = index;
             d.rec.push_back(r);
             continue;
         }
@@ -224,6 +245,51 @@ static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, u
     if (cmd_count && depth < 1) return RM_ERR_EMPTY_RESULT;
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     d.n_words = ptr;
+    *out = std::move(d);
+    return RM_OK;
+}
+
+// Decodes a program of the reference wire format (plus the extension opcodes).  A program with Material tags is
+// decoded twice: without them (`rec`, what every distance evaluation runs) and with them (`mrec`).
+static inline int rm_decode_program(uint32_t cmd_count, const uint32_t* words, uint32_t cap_words,
+                                    RmDecoded* out) {
+    bool tagged = false;
+    if (words)
+        for (uint32_t i = 0, q = 0; i < cmd_count && q < cap_words; i++) {
+            const uint32_t op = words[q++];
+            if (op == RM_CMD_MATERIAL) { tagged = true; break; }
+            q += op == RM_CMD_SPHERE || op == RM_CMD_PLANE || op == RM_CMD_ROTATION_PUSH ? 4u : op == RM_CMD_BOX ? 6u
+               : op == RM_CMD_CYLINDER ? 5u : op == RM_CMD_TRANSLATION_PUSH ? 3u
+               : op == RM_CMD_SMOOTH_UNION || op == RM_CMD_SCALE_PUSH ? 1u : 0u;
+        }
+    if (!tagged) return rm_decode_core(cmd_count, words, cap_words, false, out);
+    RmDecoded with;
+    int rc = rm_decode_core(cmd_count, words, cap_words, true, &with);  // validates everything, tags included
+    if (rc != RM_OK) return rc;
+    std::vector<uint32_t> plain;
+    plain.reserve(with.n_words);
+    uint32_t n_plain = 0;
+    for (uint32_t i = 0, q = 0; i < cmd_count; i++) {
+        const uint32_t op = words[q];
+        const uint32_t n = 1u + (op == RM_CMD_SPHERE || op == RM_CMD_PLANE || op == RM_CMD_ROTATION_PUSH ? 4u : op == RM_CMD_BOX ? 6u
+                               : op == RM_CMD_CYLINDER ? 5u : op == RM_CMD_TRANSLATION_PUSH ? 3u
+                               : op == RM_CMD_SMOOTH_UNION || op == RM_CMD_SCALE_PUSH || op == RM_CMD_MATERIAL ? 1u : 0u);
+        if (op != RM_CMD_MATERIAL) {
+            plain.insert(plain.end(), words + q, words + q + n);
+            n_plain++;
+        }
+        q += n;
+    }
+    RmDecoded d;
+    rc = rm_decode_core(n_plain, plain.data(), (uint32_t)plain.size(), false, &d);
+    if (rc != RM_OK) return rc;
+    d.n_words = with.n_words;
+    d.has_materials = true;
+    d.has_extensions = true;
+    d.max_material = with.max_material;
+    d.mat_spill_depth = with.spill_depth;
+    d.mat_xform_depth = with.xform_depth;
+    d.mrec = std::move(with.rec);
     *out = std::move(d);
     return RM_OK;
 }

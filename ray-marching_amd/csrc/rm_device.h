@@ -28,8 +28,9 @@ struct RmRecord {
 static_assert(sizeof(RmRecord) == 32, "record must be 32 bytes");
 
 enum : uint32_t { RM_KIND_POP = 0, RM_KIND_SPHERE = 1, RM_KIND_BOX = 2, RM_KIND_CYLINDER = 3, RM_KIND_PLANE = 4,
-                  RM_KIND_XFORM = 5 };  // space transformation: mode = RM_XF_*, p[0..3] = parameters (ScalePop: the scale of
+                  RM_KIND_XFORM = 5,    // space transformation: mode = RM_XF_*, p[0..3] = parameters (ScalePop: the scale of
                                         // its push), p[6] = level of the position stack
+                  RM_KIND_MATERIAL = 6 };  // material program only: the value on top takes the index in p[0] (as bits)
 enum : uint32_t { RM_MODE_PUSH = 0, RM_MODE_UNION = 1, RM_MODE_SUB = 2, RM_MODE_INTER = 3, RM_MODE_SMOOTH = 4 };
 enum : uint32_t { RM_XF_T_PUSH = 0, RM_XF_T_POP = 1, RM_XF_R_PUSH = 2, RM_XF_R_POP = 3, RM_XF_S_PUSH = 4, RM_XF_S_POP = 5 };
 enum : uint32_t { RM_MAX_XFORM_DEPTH = 8 };
@@ -47,6 +48,10 @@ enum : uint32_t { RM_CMD_PLANE = 2, RM_CMD_CYLINDER = 10, RM_CMD_INTERSECTION = 
 // Space transformations: the slots the reference reserves by comment (builder.rs:16-23).  Push(params), one child, Pop.
 enum : uint32_t { RM_CMD_TRANSLATION_PUSH = 200, RM_CMD_TRANSLATION_POP = 201, RM_CMD_ROTATION_PUSH = 202,
                   RM_CMD_ROTATION_POP = 203, RM_CMD_SCALE_PUSH = 204, RM_CMD_SCALE_POP = 205 };
+
+// Material tag (extension; the reference lists a material system as future work, README.md:11): unary postfix,
+// one u32 parameter (the index, not f32 bits).  Semantics: oracle/rm_oracle.c map_scene_impl.
+enum : uint32_t { RM_CMD_MATERIAL = 300, RM_MAX_MATERIALS = 256 };
 
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
@@ -70,6 +75,12 @@ struct RmLaunch {
     uint32_t out_format;       // enum rm_format
     unsigned long long* stats; // diagnostics (RM_OPT_WAVE_STATS): 4 x u64 per wave, or nullptr
     const uint32_t* order;     // nullptr: tiles in raster order; else dispatch slot -> tile id, per frame
+    // Materials (extension): n_mrec != 0 when the program carries Material tags.  mprog is the SAME program decoded
+    // with the tags kept (prog drops them: distances do not depend on them); a hit evaluates it once, at the hit
+    // position, on a (distance, index) stack of mat_value_depth spill slots each; materials[index].xyz = albedo.
+    const RmRecord* mprog;
+    uint32_t n_mrec, mat_value_depth;
+    const float4* materials;
     const rm_uniforms* frames; // nullptr: use `u`; else frames[blockIdx.z]
     rm_uniforms u;
 };

@@ -90,6 +90,10 @@ RMH_EXPORT rmh_node* rmh_scale(const rmh_node* child, float factor) {
     if (!child) return nullptr;
     return new (std::nothrow) rmh_node{csg::make_scale(child->node, factor)};
 }
+RMH_EXPORT rmh_node* rmh_material(const rmh_node* child, uint32_t index) {
+    if (!child) return nullptr;
+    return new (std::nothrow) rmh_node{csg::make_material(child->node, index)};
+}
 RMH_EXPORT rmh_node* rmh_node_clone(const rmh_node* n) { return n ? new (std::nothrow) rmh_node{n->node} : nullptr; }
 RMH_EXPORT void rmh_node_free(rmh_node* n) { delete n; }
 RMH_EXPORT rmh_node* rmh_scene(const char* name) {

@@ -240,7 +240,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
 
 inline const char* kernel_name() { return "rm_render_v5_spec"; }
 
-inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prune, std::string* out) {
+inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prune, bool materials, std::string* out) {
     std::string body;
     if (!generate_map_scene(rec, prune, &body)) return false;
     std::string s;
@@ -265,8 +265,8 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     }
     std::snprintf(line, sizeof line,
                   "extern \"C\" __global__ __launch_bounds__(%d) void %s(RmLaunch L, rmk::V5Work work, uint32_t n_tiles, "
-                  "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true>(L, work, n_tiles, refill_min);\n}\n",
-                  64 * wpt, kernel_name(), wpt);
+                  "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true, %s>(L, work, n_tiles, refill_min);\n}\n",
+                  64 * wpt, kernel_name(), wpt, materials ? "true" : "false");
     s += line;
     *out = std::move(s);
     return true;
@@ -389,8 +389,10 @@ public:
         return *c;
     }
     // The entry for (rec structure, wpt); queues its compilation for the worker thread the first time.
-    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt, bool prune) {
-        const std::string key = std::to_string(wpt) + (prune ? "p:" : ":") + structure_key(rec);
+    // materials: the program carries Material tags (the kernel gets the material phase; the structure is that of
+    // the untagged program)
+    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt, bool prune, bool materials) {
+        const std::string key = std::to_string(wpt) + (prune ? "p" : "") + (materials ? "m:" : ":") + structure_key(rec);
         std::unique_lock<std::mutex> lk(m_);
         auto it = entries_.find(key);
         if (it != entries_.end()) return it->second;
@@ -402,7 +404,7 @@ public:
         entries_[key] = e;
         Job job;
         job.entry = e;
-        if (!generate_source(rec, wpt, prune, &job.source)) {
+        if (!generate_source(rec, wpt, prune, materials, &job.source)) {
             e->state = Entry::FAILED;
             e->log = "program structure could not be turned into code";
             return e;

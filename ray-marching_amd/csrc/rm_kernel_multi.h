@@ -237,6 +237,81 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     for (int k = 0; k < R; k++) out[k] = acc[k];
 }
 
+// Materials (extension; semantics: oracle/rm_oracle.c map_scene_impl with mat_out).  One evaluation of the material
+// program (RmLaunch::mprog: the program decoded with its Material tags in place) at the position of a hit, on a stack
+// of (distance, index) pairs: the accumulator pair lives in registers, deeper pairs in the wave's LDS spill area
+// ([depth] distances, then [depth] indices, then 3 floats per transform level; `spill` already points at this lane).
+// Runs once per hit ray against tens of march steps, so it is a plain loop with the generic (correctly rounded)
+// square root; the distances are the ones map_scene computes at this point, operation for operation.
+RM_DEV uint32_t map_scene_material(const RmRecord* __restrict__ mprog, uint32_t n_mrec, float* spill, uint32_t value_depth,
+                                   float x, float y, float z) {
+    float acc = 0.0f;
+    uint32_t accm = 0u, sp = 0u;
+    uint32_t* mspill = reinterpret_cast<uint32_t*>(spill) + (size_t)value_depth * 64u;
+    float* saved = spill + (size_t)2u * value_depth * 64u;
+    SqrtGuard unused;
+    for (uint32_t c = 0; c < n_mrec; c++) {
+        const RmRecord& r = mprog[c];  // wave-uniform address: scalar loads
+        const uint32_t op = r.op, kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
+        float p[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) p[k] = r.p[k];
+        if (kind == RM_KIND_MATERIAL) {
+            accm = __float_as_uint(p[0]);
+            continue;
+        }
+        if (kind == RM_KIND_XFORM) {
+            float* save = saved + (size_t)3u * __float_as_uint(p[6]) * 64u;
+            if ((mode & 1u) == 0u) {
+                save[0] = x; save[64] = y; save[128] = z;
+                if (mode == RM_XF_T_PUSH) { x = x - p[0]; y = y - p[1]; z = z - p[2]; }
+                else if (mode == RM_XF_R_PUSH) xf_rotate_conj(p[0], p[1], p[2], p[3], x, y, z);
+                else { x = x / p[0]; y = y / p[0]; z = z / p[0]; }
+            } else {
+                x = save[0]; y = save[64]; z = save[128];
+                if (mode == RM_XF_S_POP) acc = acc * p[0];
+            }
+            continue;
+        }
+        float a, b;
+        uint32_t am, bm;
+        if (kind == RM_KIND_POP) {
+            --sp;
+            b = acc; bm = accm;
+            a = spill[sp * 64u]; am = mspill[sp * 64u];
+        } else {
+            if (kind == RM_KIND_SPHERE) b = sdf_sphere_t<false>(x, y, z, p, unused);
+            else if (kind == RM_KIND_BOX) b = sdf_box_t<false>(x, y, z, p, unused);
+            else if (kind == RM_KIND_CYLINDER) b = sdf_cylinder_t<false>(x, y, z, p, unused);
+            else b = ((x * p[0] + y * p[1]) + z * p[2]) + p[3];
+            bm = 0u;
+            if (op & RM_OP_SPILL) {
+                spill[sp * 64u] = acc; mspill[sp * 64u] = accm;
+                ++sp;
+            }
+            a = acc; am = accm;
+        }
+        if (mode == RM_MODE_PUSH) {
+            acc = b; accm = bm;
+        } else if (mode == RM_MODE_UNION) {
+            acc = vmin(a, b); accm = b < a ? bm : am;
+        } else if (mode == RM_MODE_SUB) {
+            acc = vmax_negb(a, b); accm = -b > a ? bm : am;
+        } else if (mode == RM_MODE_INTER) {
+            acc = fmax_(a, b); accm = b > a ? bm : am;
+        } else {  // RM_MODE_SMOOTH
+            const float kk = p[0];
+            float v = fmin_(a, b);
+            if (kk > 0.0f) {
+                const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) / kk;
+                v = v - ((h * h) * kk) * 0.25f;
+            }
+            acc = v; accm = b < a ? bm : am;
+        }
+    }
+    return accm;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Miss-ray culling (exact).  The colour of a ray that never registers a hit depends only on its
 // origin and direction (floor test, wgsl:117-130), not on the march.  A march position can only

@@ -267,7 +267,10 @@ RM_DEV bool lane_of(unsigned long long m, uint32_t lane) {
 // takes the next tile of the work list with one atomic and leaves when the list is exhausted
 // (no spinning, no inter-workgroup dependency).  Tiles whose 1024 rays are all culled never reach
 // this kernel: the pre-pass writes their pixels directly.
-template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT, bool SPEC>
+// MAT (extension, materials): compiled into the kernels that can meet a tagged program -- the extension
+// interpreter and the kernels specialised for one; it adds a fifth phase after the four normal taps of a batch of
+// hits (one evaluation of the material program at the hit positions) and a byte per ray next to its result code.
+template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT, bool SPEC, bool MAT = false>
 RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_tiles, uint32_t refill_min) {
     constexpr uint32_t POOL = 1024u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -291,6 +294,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     uint32_t* s_next = lprog + (PROG_IN_LDS ? L.n_rec * 8u : 0u);      // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
     uint32_t* s_veto = s_next + 2;
+    uint8_t* rmat = reinterpret_cast<uint8_t*>(s_next + 4);            // MAT, tagged program: [1024] material per ray
+    const bool tagged = MAT && L.n_mrec != 0u;                         // wave-uniform
+    constexpr uint32_t TAP_IDLE = MAT ? 5u : 4u;                       // tap_t: 0..3 normal taps, 4 (MAT) material, else idle
     const CullTables cullt{t_cone, t_slab, s_veto, L.n_cone, L.n_slab};
 
     rm_uniforms u = L.u;
@@ -376,7 +382,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     float thr_base = inf_f;  // SPEC: pruning threshold without its position term ("Pruning")
     // (a hit whose normal is being sampled keeps its state -- position, partial normal -- in LDS: tap phase, below)
     uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u, hq_n = 0u;  // wave-uniform cursors: ready / miss / hit buffers
-    uint32_t tap_t = 4u, tap_n = 0u;                           // wave-uniform: tap phase step (4 = not in one), its entries
+    uint32_t tap_t = TAP_IDLE, tap_n = 0u;                     // wave-uniform: tap phase step (TAP_IDLE = not in one), its entries
     bool pool_open = true;                                     // wave-uniform: the shared pool may still hold rays
 
     auto flush_misses = [&]() {  // floor / black for every waiting ray that ended without a hit (<= 64): wgsl:117-130
@@ -387,7 +393,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     };
 
     for (;;) {
-        if (tap_t == 4u) {
+        if (tap_t == TAP_IDLE) {
             // ---- A. idle lanes take ready rays; when the buffer is empty it is refilled with the
             //         survivors of the next 64 candidates of the pool ----
             const unsigned long long want0 = __ballot(mode == M_EMPTY);
@@ -458,7 +464,21 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 break;  // every lane retired, nothing waiting
             }
         }
-        const bool tapping = tap_t < 4u;  // wave-uniform
+        const bool tapping = tap_t != TAP_IDLE;  // wave-uniform
+        if constexpr (MAT) {
+            if (tap_t == 4u) {  // the normals of this batch are complete (tn): which material does each hit carry?
+                const uint32_t e = hq_n + lane;
+                const float hx = hq_v[e], hy = hq_v[V5_HQ + e], hz = hq_v[2u * V5_HQ + e];
+                const uint32_t m = map_scene_material(L.mprog, L.n_mrec, spill, L.mat_value_depth, hx, hy, hz);
+                if (lane < tap_n) {
+                    const uint32_t r = hq_rid[e];
+                    res[r] = shade_hit(tn[lane], tn[64u + lane], tn[128u + lane], hx, hy, hz);  // wgsl:98-103
+                    rmat[r] = (uint8_t)m;
+                }
+                tap_t = TAP_IDLE;
+                continue;
+            }
+        }
 
         // ---- B. one map_scene evaluation: a march step of every live ray, or normal tap tap_t of every waiting hit ----
         float ex, ey, ez, thr = inf_f;
@@ -498,8 +518,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             const float nx = tap_t == 0u ? vx : tn[lane] + vx;
             const float ny = tap_t == 0u ? vy : tn[64u + lane] + vy;
             const float nz = tap_t == 0u ? vz : tn[128u + lane] + vz;
-            if (++tap_t == 4u) {
+            if (++tap_t == 4u && !tagged) {
                 if (is_live) res[hq_rid[he]] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
+                tap_t = TAP_IDLE;
             } else {
                 tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
             }
@@ -556,6 +577,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 float cr, cg, cb;
                 if (code >= 0.0f) {  // hit: (0.4,0.7,0.1) * k  (wgsl:105)
                     cr = 0.4f * code; cg = 0.7f * code; cb = 0.1f * code;
+                    if constexpr (MAT) {
+                        if (tagged) {  // extension: the albedo of the material the surface carries
+                            const float4 al = L.materials[rmat[s * 64u + p]];
+                            cr = al.x * code; cg = al.y * code; cb = al.z * code;
+                        }
+                    }
                 } else if (code > -2.5f) {  // floor (wgsl:127)
                     const float g = 0.2f * (-1.0f - code);
                     cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
@@ -586,7 +613,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 
 template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT>
 __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
-    rm_render_v5_body<Prog, PROG_IN_LDS, WPT, EXT, false>(L, work, n_tiles, refill_min);
+    rm_render_v5_body<Prog, PROG_IN_LDS, WPT, EXT, false, EXT>(L, work, n_tiles, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------

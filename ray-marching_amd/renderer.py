@@ -68,6 +68,11 @@ class RayMarchingResources:
         ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if n else None
         self._check(self._L.rm_set_program(self._h, int(cmd_count), ptr, n))
 
+    def set_materials(self, rgb):
+        """Material table (extension): (n, 3) albedo values, n in [1, 256]; entry i colours the surfaces tagged Material(i)."""
+        m = np.ascontiguousarray(np.asarray(rgb, dtype=np.float32).reshape(-1, 3))
+        self._check(self._L.rm_set_materials(self._h, len(m), m.ctypes.data_as(C.POINTER(C.c_float))))
+
     def set_scene(self, node):
         self.set_program(*_csg.serialize(node))
 

@@ -35,6 +35,7 @@ CASES = [
     ("g32s_64", "g32s", 64, 64, (0.01, 100.0, 256), scenes.STILL_CAMERA_EVENTS),
     ("ext_mix_64x48", "ext_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),
     ("xform_mix_64x48", "xform_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),   # space transformations
+    ("mat_mix_64x48", "mat_mix", 64, 48, (0.01, 100.0, 128), scenes.STILL_CAMERA_EVENTS),       # material tags + table
 ]
 # larger renders pinned by checksum + counters only
 BIG = [
@@ -48,7 +49,7 @@ def inputs(scene, W, H, events):
     if scene is None:
         cc, words = 0, np.zeros(0, dtype=np.uint32)
     else:
-        cc, words = cbind.serialize(*{**scenes.SCENES, **scenes.EXT_SCENES}[scene]())
+        cc, words = cbind.serialize(*{**scenes.SCENES, **scenes.EXT_SCENES, **scenes.MAT_SCENES}[scene]())
     u, *_ = cbind.orbit_uniforms((float(W), float(H)), events=events)
     return cc, words, u
 
@@ -57,7 +58,8 @@ def main():
     index = {}
     for name, scene, W, H, lim, events in CASES + BIG:
         cc, words, u = inputs(scene, W, H, events)
-        img, cnt = cbind.render(u, lim, cc, words, W, H, threads=8, want_counters=True)
+        table = scenes.MATERIAL_TABLE if scene in scenes.MAT_SCENES else None
+        img, cnt = cbind.render(u, lim, cc, words, W, H, threads=8, want_counters=True, materials=table)
         entry = {
             "scene": scene, "W": W, "H": H, "limits": list(lim), "cmd_count": cc,
             "words": [int(x) for x in words],
@@ -65,6 +67,8 @@ def main():
             "sha256": hashlib.sha256(img.tobytes()).hexdigest(),
             "counters": cnt,
         }
+        if table is not None:
+            entry["materials"] = [[float(np.float32(c)) for c in m] for m in table]
         if (name, scene, W, H, lim, events) in CASES:
             np.save(os.path.join(HERE, name + ".npy"), img)
             entry["file"] = name + ".npy"

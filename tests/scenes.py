@@ -5,6 +5,7 @@ flat-table form oracle.cbind.serialize() takes."""
 SPHERE, BOX, UNION, SUBTRACTION = 0, 1, 100, 101
 PLANE, CYLINDER, INTERSECTION, SMOOTH_UNION = 2, 10, 102, 110    # extension node types
 TRANSLATION, ROTATION, SCALE = 200, 202, 204                     # space transformations (push opcode; child = lhs)
+MATERIAL = 300                                                   # material tag (extension; child = lhs, params = [index])
 
 
 def _f32(x):
@@ -51,6 +52,10 @@ class _Tab:
 
     def smooth_union(self, a, b, k):
         self.nodes.append((SMOOTH_UNION, [k], a, b))
+        return len(self.nodes) - 1
+
+    def material(self, child, index):
+        self.nodes.append((MATERIAL, [index], child, -1))
         return len(self.nodes) - 1
 
 
@@ -179,8 +184,28 @@ def xform_mix():
     return t.nodes, t.op(UNION, t.op(UNION, t.op(UNION, a, b), c), d)
 
 
+MATERIAL_TABLE = [(0.4, 0.7, 0.1), (0.9, 0.15, 0.1), (0.1, 0.3, 0.9), (0.95, 0.9, 0.2), (0.8, 0.8, 0.8), (0.6, 0.1, 0.7)]
+
+
+def mat_mix():
+    """Material tags (extension) on leaves, on a sub-tree, inside transform scopes, under every operator: the carved
+    surfaces of a subtraction show the subtractor's material, a blend switches where the operands cross."""
+    t = _Tab()
+    h = 0.70710678
+    body = t.op(UNION, t.material(t.sphere((0, 0, 0), 1.0), 1), t.material(t.box((0, 0, 0), (0.8, 0.8, 0.8)), 2))
+    carved = t.op(SUBTRACTION, body, t.material(t.sphere((0.9, 0.5, 0.6), 0.6), 3))
+    slab = t.box((0, -1.2, 0), (1.5, 0.1, 1.5))                                    # untagged: material 0
+    arm = t.translation(t.rotation(t.material(t.cylinder((0, 0, 0), 0.25, 0.9), 5), (h, 0, 0, h)), (-1.3, 0.4, 0.3))
+    blob = t.material(t.smooth_union(t.material(t.sphere((1.3, 0.2, -0.6), 0.45), 1), t.sphere((1.7, 0.5, -0.3), 0.35), 0.3), 4)
+    cut = t.op(INTERSECTION, t.material(t.box((-0.2, 1.3, -0.9), (0.5, 0.5, 0.5)), 2), t.material(t.sphere((-0.2, 1.3, -0.9), 0.62), 3))
+    twin = t.scale(t.smooth_union(t.material(t.sphere((-2.0, -0.6, 1.6), 0.5), 3), t.material(t.box((-1.2, -0.6, 1.6), (0.4, 0.4, 0.4)), 5), 0.4), 0.8)
+    root = t.op(UNION, t.op(UNION, t.op(UNION, t.op(UNION, t.op(UNION, carved, slab), arm), blob), cut), twin)
+    return t.nodes, root
+
+
 SCENES = {"g1": g1, "g8": g8, "g32": g32, "g64": g64, "g32_balanced": g32_balanced}
 EXT_SCENES = {"g8x": g8x, "g32s": g32s, "ext_mix": ext_mix, "xform_mix": xform_mix}
+MAT_SCENES = {"mat_mix": mat_mix}    # need MATERIAL_TABLE
 
 # (events for OrbitCameraController::update) still camera of SURVEY 8(d): Orbit([35,-25])
 STILL_CAMERA_EVENTS = [(1, 35.0, -25.0)]

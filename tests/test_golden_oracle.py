@@ -16,7 +16,7 @@ def test_oracle_reproduces_golden(oracle, name):
     e = IDX[name]
     u = oracle.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
     img, cnt = oracle.render(u, tuple(e["limits"]), e["cmd_count"], G.words(e), e["W"], e["H"], threads=4,
-                             want_counters=True)
+                             want_counters=True, materials=e.get("materials"))
     assert hashlib.sha256(img.tobytes()).hexdigest() == e["sha256"]
     assert cnt == e["counters"]
     if "file" in e:

@@ -12,8 +12,15 @@ from ray_marching_amd import _ffi, renderer
 pytestmark = pytest.mark.gpu
 
 
-def random_tree(rng, t, depth, allow_plane):
-    """Returns a node index of a random sub-tree built into table t."""
+def random_tree(rng, t, depth, allow_plane, tags=False):
+    """Returns a node index of a random sub-tree built into table t (tags: a quarter of the nodes get a material tag)."""
+    node = _random_tree(rng, t, depth, allow_plane, tags)
+    if tags and rng.random() < 0.25:
+        node = t.material(node, int(rng.integers(0, 8)))
+    return node
+
+
+def _random_tree(rng, t, depth, allow_plane, tags):
     r = rng.random()
     if depth == 0 or r < 0.28:
         kind = rng.integers(0, 4 if allow_plane else 3)
@@ -28,7 +35,7 @@ def random_tree(rng, t, depth, allow_plane):
         n /= np.linalg.norm(n)
         return t.plane(tuple(n), float(rng.uniform(0.5, 2.0)))
     if r < 0.50:   # a transform around a sub-tree
-        child = random_tree(rng, t, depth - 1, allow_plane)
+        child = random_tree(rng, t, depth - 1, allow_plane, tags)
         k = rng.integers(0, 3)
         if k == 0:
             return t.translation(child, tuple(rng.uniform(-0.8, 0.8, 3)))
@@ -38,8 +45,8 @@ def random_tree(rng, t, depth, allow_plane):
             ang = rng.uniform(-math.pi, math.pi)
             return t.rotation(child, (math.cos(ang / 2), *(math.sin(ang / 2) * ax)))
         return t.scale(child, float(rng.uniform(0.5, 1.8)))
-    a = random_tree(rng, t, depth - 1, allow_plane)
-    b = random_tree(rng, t, depth - 1, allow_plane)
+    a = random_tree(rng, t, depth - 1, allow_plane, tags)
+    b = random_tree(rng, t, depth - 1, allow_plane, tags)
     op = rng.choice(["u", "s", "i", "m"], p=[0.45, 0.25, 0.1, 0.2])
     if op == "m":
         return t.smooth_union(a, b, float(rng.choice([rng.uniform(0.05, 0.9), 0.0, -0.2], p=[0.9, 0.05, 0.05])))
@@ -60,7 +67,9 @@ def test_random_programs_against_the_oracle(oracle, seed):
         res.resize_command_buffer(8192)
         for _ in range(3):
             t = scenes._Tab()
-            root = random_tree(rng, t, int(rng.integers(1, 5)), allow_plane=bool(rng.random() < 0.3))
+            tags = bool(rng.random() < 0.4)
+            table = rng.uniform(0.0, 1.0, (8, 3)).astype(np.float32) if tags else None
+            root = random_tree(rng, t, int(rng.integers(1, 5)), allow_plane=bool(rng.random() < 0.3), tags=tags)
             cc, w = oracle.serialize(t.nodes, root)
             rc, _ = oracle.validate(cc, w)
             prc, _ = renderer.validate_program(cc, w)
@@ -70,7 +79,8 @@ def test_random_programs_against_the_oracle(oracle, seed):
             events = [(1, float(rng.uniform(-300, 300)), float(rng.uniform(-140, 140))), (2, float(rng.uniform(-60, 150)), 0.0)]
             u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
             lim = (float(rng.choice([0.01, 0.2])), 100.0, int(rng.choice([24, 64])))
-            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4, materials=table)
+            res.set_materials(table if tags else [(0.4, 0.7, 0.1)])
             res.set_limits(lim)
             res.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
             res.set_program(cc, w)

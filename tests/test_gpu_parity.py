@@ -45,13 +45,14 @@ def assert_same(img, ref):
                              % (np.nanmax(d), TOLERANCE, len(bad), d.shape[0] * d.shape[1], bad[:4].tolist()))
 
 
-def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kernel=_ffi.RM_KERNEL_DEFAULT):
+def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kernel=_ffi.RM_KERNEL_DEFAULT, materials=None):
     spec = kernel in (KERNEL_SPEC, KERNEL_SPEC_PRUNE, _ffi.RM_KERNEL_DEFAULT)
     res.set_option(_ffi.RM_OPT_SPECIALIZE, 2 if spec else 0)
     res.set_option(_ffi.RM_OPT_PRUNE, 1 if kernel == KERNEL_SPEC_PRUNE else 0)
     res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5_LDS if kernel in (KERNEL_SPEC, KERNEL_SPEC_PRUNE) else kernel)
     res.set_limits(limits)
     res.set_uniforms(u)
+    res.set_materials(materials if materials is not None else [(0.4, 0.7, 0.1)])
     res.set_program(cc, words)
 
 
@@ -59,10 +60,10 @@ def setup(res, e_or_none=None, *, cc=None, words=None, u=None, limits=None, kern
 @pytest.mark.parametrize("name", sorted(n for n in IDX if "file" in IDX[n]))
 def test_golden_fixtures(res, name, kernel):
     e = IDX[name]
-    if e["scene"] in scenes.EXT_SCENES and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE):
+    if (e["scene"] in scenes.EXT_SCENES or e["scene"] in scenes.MAT_SCENES) and kernel not in (_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE):
         pytest.skip("only the v5 kernels render extension node types")
     u = _ffi.Uniforms.from_buffer_copy(G.uniforms_bytes(e))
-    setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel)
+    setup(res, cc=e["cmd_count"], words=G.words(e), u=u, limits=tuple(e["limits"]), kernel=kernel, materials=e.get("materials"))
     assert_same(res.draw(e["W"], e["H"]), G.load_image(e))
 
 
