@@ -47,6 +47,7 @@ extern "C" {
     pub fn rm_set_uniforms(ctx: *mut rm_ctx, u: *const rm_uniforms) -> c_int;
     pub fn rm_set_limits(ctx: *mut rm_ctx, l: *const rm_limits) -> c_int;
     pub fn rm_set_program(ctx: *mut rm_ctx, cmd_count: u32, words: *const u32, n_words: u32) -> c_int;
+    pub fn rm_set_materials(ctx: *mut rm_ctx, count: u32, rgb: *const f32) -> c_int; // extension: count x 3 floats
     pub fn rm_resize_command_buffer(ctx: *mut rm_ctx, bytes: u64) -> c_int;
     pub fn rm_validate(ctx: *mut rm_ctx) -> c_int;
     pub fn rm_validate_program(cmd_count: u32, words: *const u32, n_words: u32, out_max_depth: *mut u32) -> c_int;

@@ -16,11 +16,25 @@ p.add_argument("--scene", default="g32")
 p.add_argument("--max-iter", type=int, default=256)
 p.add_argument("--specialize", type=int, default=2)
 p.add_argument("--steps", type=int, default=40)
+p.add_argument("--strip-tags", action="store_true", help="render the scene without its Material tags (cost of the material phase)")
 a = p.parse_args()
 res = renderer.RayMarchingResources(0)
 res.set_option(_ffi.RM_OPT_SPECIALIZE, a.specialize)
 res.set_limits(renderer.RayMarchLimits(0.01, 100.0, a.max_iter))
-res.set_scene(csg.scene(a.scene))
+import numpy as np  # noqa: E402
+cc, words = csg.serialize(csg.scene(a.scene))
+if a.strip_tags:
+    n_par = {0: 4, 1: 6, 2: 4, 10: 5, 110: 1, 200: 3, 202: 4, 204: 1, 300: 1}
+    kept, i, cc = [], 0, 0
+    while i < len(words):
+        n = 1 + n_par.get(int(words[i]), 0)
+        if int(words[i]) != 300:
+            kept += [int(x) for x in words[i:i + n]]
+            cc += 1
+        i += n
+    words = np.array(kept, dtype=np.uint32)
+res.set_materials([(0.4, 0.7, 0.1), (0.9, 0.15, 0.1), (0.1, 0.3, 0.9), (0.95, 0.9, 0.2), (0.8, 0.8, 0.8), (0.6, 0.1, 0.7), (0.2, 0.2, 0.2), (1.0, 1.0, 1.0)])
+res.set_program(cc, words)
 ctl = camera.OrbitCameraController.new([0, 0, 0], 5.0)
 ctl.update(camera.Orbit([35.0, -25.0]))
 res.set_uniforms(renderer.prepare_uniforms((a.width, a.height), ctl.camera()))
