@@ -331,6 +331,7 @@ def main():
                 line["compute"] = {"map_scene_evals_per_frame": evals,
                                    "evals_per_s": evals / (kernel_ms * 1e-3),
                                    "note": "evaluations counted by the oracle on the CPU sample, scaled by pixel count"}
+                line["compute"].update(valu_view(args, res, serial["kernel_ms"] if serial else kernel_ms, evals, words))
         print(json.dumps(line), flush=True)
     for c in ctxs:
         c.close()
@@ -338,6 +339,46 @@ def main():
         shared.close((lambda: dist.barrier(group=gloo)) if world > 1 else None)
     if world > 1:
         dist.destroy_process_group()
+
+
+def valu_view(args, res, march_ms, evals, words):
+    """The honest bound: FP32 vector issue.  Instruction counts come from the committed PMC pass of this
+    configuration (profiles/pmc_traffic.json), the duration from this run (march kernel, no other frame in flight)."""
+    from ray_marching_amd import _ffi
+    out = {}
+    # algorithmic flops of the reference's map_scene for this program (SURVEY 8(d): 10 / sphere, 22 / box, 1 / union,
+    # 2 / subtraction), times the evaluations the REFERENCE would make (the GPU skips those of rays it proves to miss)
+    f_prog, i = 0, 0
+    per_op = {0: (10, 4), 1: (22, 6), 100: (1, 0), 101: (2, 0)}
+    while i < len(words):
+        fl, n = per_op.get(int(words[i]), (0, 0))
+        f_prog += fl
+        i += 1 + n
+    out["flops_per_eval_reference"] = f_prog
+    out["algorithmic_TFLOPs"] = evals * f_prog / (march_ms * 1e-3) / 1e12
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pmc = json.load(fh).get("%s_%dx%d_%d_valu" % (args.scene, args.width, args.height, args.max_iter))
+    except (OSError, ValueError):
+        pmc = None
+    if pmc:
+        simds = 4.0 * res.info(_ffi.RM_INFO_CU_COUNT)
+        insts = pmc["SQ_INSTS_VALU"]
+        flop_insts = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + pmc["SQ_INSTS_VALU_TRANS_F32"]
+        ns_per_inst = march_ms * 1e6 * simds / insts
+        out.update({
+            "bound": "fp32 valu issue",
+            "valu_insts_per_frame": insts,
+            "ns_per_valu_inst_per_simd": ns_per_inst,
+            "fastest_valu_issue_ns_per_simd": pmc["fastest_valu_issue_ns_per_simd"],
+            "frac_of_valu_issue": pmc["fastest_valu_issue_ns_per_simd"] / ns_per_inst,
+            "executed_fp32_TFLOPs": flop_insts * 64.0 * pmc["lane_occupancy"] / (march_ms * 1e-3) / 1e12,
+            "peak_fp32_vector_TFLOPs": 157.3,
+            "valu_note": "instruction counts: committed rocprofv3 PMC pass of this configuration; issue floor: fastest class of "
+                         "profiles/r01_ubench_valu_issue_rates.txt (v_add / v_mul / v_fma; min / max / cmp / transcendental ops issue "
+                         "slower); the 157.3 TFLOP/s peak assumes packed FMAs, the contract forbids fusing (DESIGN 2)",
+        })
+    return out
 
 
 if __name__ == "__main__":
