@@ -262,7 +262,16 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
             hipModuleGetFunction(&fn, mod, rmjit::kernel_name()) == hipSuccess) {
             l.module = mod;
             l.function = fn;
-            e->unload = [](void* m) { (void)hipModuleUnload(static_cast<hipModule_t>(m)); };
+            // an evicted entry (more than 256 structures in one process) may still have launches in flight on a
+            // context that moved on to another program: wait for the device before the code object goes away
+            e->unload = [](void* m, int device) {
+                int current = -1;
+                if (hipGetDevice(&current) != hipSuccess) current = -1;
+                if (hipSetDevice(device) == hipSuccess) (void)hipDeviceSynchronize();
+                (void)hipModuleUnload(static_cast<hipModule_t>(m));
+                if (current >= 0) (void)hipSetDevice(current);
+                (void)hipGetLastError();
+            };
         } else {
             (void)hipGetLastError();
             if (mod) (void)hipModuleUnload(mod);

@@ -362,7 +362,7 @@ struct Entry {
     // Filled by the caller's (HIP) thread under `m`: device ordinal -> {hipModule_t, hipFunction_t}.
     struct Loaded { void* module = nullptr; void* function = nullptr; };
     std::map<int, Loaded> loaded;
-    void (*unload)(void* module) = nullptr;  // hipModuleUnload, set by whoever loads
+    void (*unload)(void* module, int device) = nullptr;  // waits for the device, then hipModuleUnload; set by whoever loads
 
     State wait() {
         std::unique_lock<std::mutex> lk(m);
@@ -376,7 +376,7 @@ struct Entry {
     ~Entry() {
         if (unload)
             for (auto& kv : loaded)
-                if (kv.second.module) unload(kv.second.module);
+                if (kv.second.module) unload(kv.second.module, kv.first);
     }
 };
 

@@ -41,6 +41,19 @@ int main(int argc, char** argv) {
             return 4;
         }
         std::printf("specialised %d jit_ms %.0f\n", (int)specialised, jit_ms);
+        // Extension: a tagged scene built with the C++ node types and a material table (argv[2] receives the frame).
+        if (argc > 2) {
+            const float table[6][3] = {{0.4f, 0.7f, 0.1f}, {0.9f, 0.15f, 0.1f}, {0.1f, 0.3f, 0.9f},
+                                       {0.95f, 0.9f, 0.2f}, {0.8f, 0.8f, 0.8f}, {0.6f, 0.1f, 0.7f}};
+            resources.check(rm_set_materials(resources.ctx(), 6, &table[0][0]));
+            auto tagged = RayMarchingCallback::new_(0.0f, scenes::mat_mix(), {(float)W, (float)H}, controller.camera());
+            tagged.prepare(resources);
+            tagged.paint(resources, W, H, again.data());
+            FILE* f = std::fopen(argv[2], "wb");
+            if (!f) return 3;
+            std::fwrite(again.data(), 4, again.size(), f);
+            std::fclose(f);
+        }
         // None scene: cmd_count = 0 (renderer.rs:224-227)
         auto none_cb = RayMarchingCallback::new_(0.0f, std::nullopt, {(float)W, (float)H}, controller.camera());
         none_cb.prepare(resources);
