@@ -184,7 +184,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
             const int b = stack.back(); stack.pop_back();
             const int a = stack.back(); stack.pop_back();
             const int w = nv++;
-            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d);\n", w, off, a, b);
+            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d, live);\n", w, off, a, b);
             else if (op) std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, v%d);\n", w, op, a, b);
             else return false;
             s += line;

@@ -118,11 +118,17 @@ RM_DEV float spec_cylinder(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny
 RM_DEV float spec_plane(LdsF r, float qx, float qy, float qz) {
     return ((qx * r[0] + qy * r[1]) + qz * r[2]) + r[3];  // as exec_command
 }
-RM_DEV float spec_smooth_union(LdsF r, float a, float b) {  // as exec_command, RM_MODE_SMOOTH
+RM_DEV float spec_smooth_union(LdsF r, float a, float b, bool live) {  // as exec_command, RM_MODE_SMOOTH
     const float kk = r[0];
     float v = fmin_(a, b);
     if (kk > 0.0f) {
-        const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) / kk;
+        const float t = kk - __builtin_fabsf(a - b);
+        // Outside the blend zone (t <= 0, or NaN) h is 0 and, k being finite, the result is v - 0 = v exactly.  When
+        // that holds for every live lane of the wave -- most evaluations: two operands are within k of each other
+        // only near the seams -- the division and the five operations after it are skipped (dead lanes' values are
+        // never used).
+        if (kk < __uint_as_float(0x7F800000u) && __ballot(live && t > 0.0f) == 0ull) return v;
+        const float h = fmax_(t, 0.0f) / kk;
         v = v - ((h * h) * kk) * 0.25f;
     }
     return v;
