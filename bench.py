@@ -39,7 +39,9 @@ def parse():
                    help="structure specialisation of the march kernel (hipRTC): 0 interpreter kernel only, 1 compile in the "
                         "background, 2 compile when the scene is uploaded (default: the scene is static, so the one-off "
                         "compilation happens before the warm-up, like the reference's own shader compilation)")
-    p.add_argument("--prune", action="store_true", help="A/B: specialised kernel with far-primitive pruning (exact; measured slower)")
+    p.add_argument("--prune", type=int, default=-1, choices=[-1, 0, 1, 2],
+                   help="far-primitive pruning in the specialised kernel (exact): 0 off, 1 on, 2 for programs with >= 24 primitives; "
+                        "-1 (default) leaves the library default (2)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
     p.add_argument("--balance", type=int, default=-1, help="A/B: RM_OPT_BALANCE value (0 raster, 1 fullest tiles first, 2 silhouette tiles first)")
@@ -132,8 +134,8 @@ def main():
         r = renderer.RayMarchingResources(local_rank)
         r.set_option(_ffi.RM_OPT_KERNEL, args.kernel)
         r.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
-        if args.prune:
-            r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        if args.prune >= 0:
+            r.set_option(_ffi.RM_OPT_PRUNE, args.prune)
         if args.refill_min:
             r.set_option(_ffi.RM_OPT_REFILL_MIN, args.refill_min)
         if args.waves_per_tile:

@@ -120,9 +120,10 @@ enum rm_option {
     RM_OPT_OUTPUT_FORMAT = 10, /* enum rm_format: what rm_draw / rm_draw_strips / rm_draw_batch write (default RM_FORMAT_RGBA32F).
                                   The 8-bit formats are the output stage of SURVEY 8(f)-3: the reference's own colour target is
                                   the 8-bit egui surface (renderer.rs:113).  Only the default (v5) kernels implement them. */
-    RM_OPT_PRUNE = 9,      /* specialised kernels: 1 = skip, per wave and per march step, primitives that provably cannot
-                              influence the scene value there (exact; DESIGN.md "Pruning").  Default 0: on MI355X the
-                              wave-uniform tests cost more than the skipped work saves (measured) */
+    RM_OPT_PRUNE = 9,      /* specialised kernels: skip, per wave and per march step, primitives that provably cannot
+                              influence the scene value there (exact; DESIGN.md "Pruning"): 0 never, 1 always, 2 (default)
+                              for programs with at least 24 spheres + boxes -- on MI355X the wave-uniform tests cost about
+                              what they save at 16 primitives (-0.4 %) and pay from there on (+4 to +5 % at 32) */
     RM_OPT_SPECIALIZE = 8  /* structure specialisation of the default (v5) march kernel: the command sequence is compiled
                               into straight-line code with hipRTC, once per program STRUCTURE (parameters stay data);
                               results are bit-identical to the interpreter kernel.
@@ -163,7 +164,8 @@ enum rm_info {
     RM_INFO_SPECIALIZED = 6,     /* 1 if the last march launch ran a structure-specialised kernel, else 0 */
     RM_INFO_JIT_STATE = 7,       /* specialisation of the current program: 0 none requested, 1 compiling, 2 ready, 3 failed
                                     (rm_jit_log has the reason) */
-    RM_INFO_JIT_COMPILE_MS = 8   /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
+    RM_INFO_JIT_COMPILE_MS = 8,  /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
+    RM_INFO_PRUNED = 9           /* 1 when the kernel requested for the current program is the pruned form (RM_OPT_PRUNE) */
 };
 
 int rm_abi_version(void);

@@ -28,6 +28,7 @@ constexpr uint64_t kRefCmdBufferBytes = 1024;  // renderer.rs:142-147
 constexpr uint64_t kMaxCmdBufferBytes = 65536;
 constexpr uint32_t kMaxDim = 1u << 16;
 constexpr uint32_t kMaxIter = 1u << 16;
+constexpr uint32_t kPruneLeaves = 24;  // RM_OPT_PRUNE = 2: programs with this many spheres + boxes get the pruned kernel
 
 thread_local std::string g_create_error;
 
@@ -90,11 +91,13 @@ struct rm_ctx {
     // ready, 2 wait for the compiler at the first draw of a new structure
     int specialize = 1;
     int out_format = RM_FORMAT_RGBA32F;  // RM_OPT_OUTPUT_FORMAT
-    bool prune = false;  // RM_OPT_PRUNE: far-primitive pruning in specialised kernels (measured slower: off)
+    int prune = 2;  // RM_OPT_PRUNE: far-primitive pruning in specialised kernels: 0 off, 1 on, 2 (default) on for programs
+                    // with at least kPruneLeaves spheres + boxes (measured: 16 leaves -0.4 %, 32 leaves +4 to +5 %)
     uint64_t prog_gen = 0;  // bumped whenever the decoded program changes
     std::shared_ptr<rmjit::Entry> spec;
     uint64_t spec_gen = ~0ull;
     int spec_wpt = 0;
+    bool spec_pruned = false;
     bool last_specialized = false;  // the last march launch ran a specialised kernel
     // stream-ordered uploads (program records, bounds, batch uniforms): four pinned staging buffers, see upload()
     struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
@@ -245,7 +248,10 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
     if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
-        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, c->prune && c->decoded.prunable, c->decoded.has_materials);
+        const bool prune = c->decoded.prunable &&
+                           (c->prune == 1 || (c->prune == 2 && c->decoded.n_sphere + c->decoded.n_box >= kPruneLeaves));
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, prune, c->decoded.has_materials);
+        c->spec_pruned = prune;
         c->spec_gen = c->prog_gen;
         c->spec_wpt = wpt;
     }
@@ -883,7 +889,11 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     case RM_OPT_CULL: c->cull = value != 0; return RM_OK;
     case RM_OPT_BALANCE: c->balance = value < 0 ? 0 : value > 3 ? 3 : (int)value; c->measured_shape = 0; return RM_OK;
     case RM_OPT_WAVE_STATS: c->wave_stats = value != 0; return RM_OK;
-    case RM_OPT_PRUNE: c->prune = value != 0; c->spec_gen = ~0ull; return RM_OK;
+    case RM_OPT_PRUNE:
+        if (value < 0 || value > 2) return fail(c, RM_ERR_ARG, "RM_OPT_PRUNE: %lld is not 0, 1 or 2", (long long)value);
+        c->prune = (int)value;
+        c->spec_gen = ~0ull;
+        return RM_OK;
     case RM_OPT_OUTPUT_FORMAT:
         if (value < RM_FORMAT_RGBA32F || value > RM_FORMAT_BGRA8_UNORM) return fail(c, RM_ERR_ARG, "unknown output format %lld", (long long)value);
         c->out_format = (int)value;
@@ -925,6 +935,7 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     case RM_INFO_DEVICE: *out = c->device; return RM_OK;
     case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
     case RM_INFO_SPECIALIZED: *out = c->last_specialized ? 1.0 : 0.0; return RM_OK;
+    case RM_INFO_PRUNED: *out = c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty && c->spec_pruned ? 1.0 : 0.0; return RM_OK;
     case RM_INFO_JIT_STATE:
     case RM_INFO_JIT_COMPILE_MS: {
         *out = 0.0;

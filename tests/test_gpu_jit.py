@@ -189,3 +189,28 @@ def test_full_size_metric_config_specialised_vs_interpreter(res, oracle):
     assert res.draw(W, H).tobytes() == a.tobytes()
     for r0, rows in [(200, 3), (540, 4), (901, 3)]:
         assert b[r0:r0 + rows].tobytes() == oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=8).tobytes()
+
+
+def test_pruning_policy_by_primitive_count(oracle):
+    """RM_OPT_PRUNE = 2 (the default): the pruned form of the generated kernel for programs with at least 24 spheres +
+    boxes (G64: 32), the plain form below that (G32: 16); 0 / 1 force it; every form renders the oracle's image."""
+    W, H = 64, 40
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_limits(LIM)
+        for name, want in (("g32", {2: 0, 1: 1, 0: 0}), ("g64", {2: 1, 1: 1, 0: 0})):
+            cc, w, u = case(oracle, ALL[name](), W, H)
+            ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
+            r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+            r.set_program(cc, w)
+            for mode in (2, 1, 0):           # a fresh context starts at 2
+                if mode != 2:
+                    r.set_option(_ffi.RM_OPT_PRUNE, mode)
+                assert r.draw(W, H).tobytes() == ref.tobytes(), (name, mode)
+                assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == want[mode], (name, mode)
+            r.set_option(_ffi.RM_OPT_PRUNE, 2)
+        with pytest.raises(_ffi.RmError):
+            r.set_option(_ffi.RM_OPT_PRUNE, 3)
+    finally:
+        r.close()
