@@ -40,7 +40,7 @@ def parse():
                         "background, 2 compile when the scene is uploaded (default: the scene is static, so the one-off "
                         "compilation happens before the warm-up, like the reference's own shader compilation)")
     p.add_argument("--prune", type=int, default=-1, choices=[-1, 0, 1, 2],
-                   help="far-primitive pruning in the specialised kernel (exact): 0 off, 1 on, 2 for programs with >= 24 primitives; "
+                   help="far-primitive pruning in the specialised kernel (exact): 0 off, 1 on, 2 for programs with >= 12 primitives; "
                         "-1 (default) leaves the library default (2)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
     p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
@@ -57,7 +57,7 @@ def parse():
                         "process group; shm = every rank copies its strips into one shared-memory image (never RCCL)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-ab", action="store_true", help="skip the serial and interpreter-kernel legs that follow the timed region")
-    p.add_argument("--frames-in-flight", type=int, default=3,
+    p.add_argument("--frames-in-flight", type=int, default=4,
                    help="frames drawn concurrently, each on its own context / stream / output buffer (1 = strictly serial)")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
     return p.parse_args()

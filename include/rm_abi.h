@@ -122,8 +122,8 @@ enum rm_option {
                                   the 8-bit egui surface (renderer.rs:113).  Only the default (v5) kernels implement them. */
     RM_OPT_PRUNE = 9,      /* specialised kernels: skip, per wave and per march step, primitives that provably cannot
                               influence the scene value there (exact; DESIGN.md "Pruning"): 0 never, 1 always, 2 (default)
-                              for programs with at least 24 spheres + boxes -- on MI355X the wave-uniform tests cost about
-                              what they save at 16 primitives (-0.4 %) and pay from there on (+4 to +5 % at 32) */
+                              for programs with at least 12 spheres + boxes -- on MI355X the wave-uniform tests cost more
+                              than they save at 4 primitives (-6 %) and pay from there on (+6 % at 16, +14 % at 32) */
     RM_OPT_SPECIALIZE = 8  /* structure specialisation of the default (v5) march kernel: the command sequence is compiled
                               into straight-line code with hipRTC, once per program STRUCTURE (parameters stay data);
                               results are bit-identical to the interpreter kernel.

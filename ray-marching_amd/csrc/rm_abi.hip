@@ -28,7 +28,7 @@ constexpr uint64_t kRefCmdBufferBytes = 1024;  // renderer.rs:142-147
 constexpr uint64_t kMaxCmdBufferBytes = 65536;
 constexpr uint32_t kMaxDim = 1u << 16;
 constexpr uint32_t kMaxIter = 1u << 16;
-constexpr uint32_t kPruneLeaves = 24;  // RM_OPT_PRUNE = 2: programs with this many spheres + boxes get the pruned kernel
+constexpr uint32_t kPruneLeaves = 12;  // RM_OPT_PRUNE = 2: programs with this many spheres + boxes get the pruned kernel
 
 thread_local std::string g_create_error;
 
@@ -92,7 +92,7 @@ struct rm_ctx {
     int specialize = 1;
     int out_format = RM_FORMAT_RGBA32F;  // RM_OPT_OUTPUT_FORMAT
     int prune = 2;  // RM_OPT_PRUNE: far-primitive pruning in specialised kernels: 0 off, 1 on, 2 (default) on for programs
-                    // with at least kPruneLeaves spheres + boxes (measured: 16 leaves -0.4 %, 32 leaves +4 to +5 %)
+                    // with at least kPruneLeaves spheres + boxes (measured: 4 leaves -6 %, 16 leaves +6 %, 32 leaves +14 %)
     uint64_t prog_gen = 0;  // bumped whenever the decoded program changes
     std::shared_ptr<rmjit::Entry> spec;
     uint64_t spec_gen = ~0ull;

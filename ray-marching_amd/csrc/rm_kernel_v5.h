@@ -477,7 +477,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 const float hx = hq_v[e], hy = hq_v[V5_HQ + e], hz = hq_v[2u * V5_HQ + e];
                 const uint32_t m = map_scene_material(L.mprog, L.n_mrec, spill, L.mat_value_depth, hx, hy, hz);
                 if (lane < tap_n) {
-                    const uint32_t r = hq_rid[e];
+                    const uint32_t r = hq_rid[e] & 1023u;
                     res[r] = shade_hit(tn[lane], tn[64u + lane], tn[128u + lane], hx, hy, hz);  // wgsl:98-103
                     rmat[r] = (uint8_t)m;
                 }
@@ -497,6 +497,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
             ez = hq_v[2u * V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgz);
             is_live = lane < tap_n;
+#ifdef RM_JIT_PRUNE_ON
+            // the tap is eps * sqrt(3) away from the hit position, where the scene value was sd_hit ("Pruning")
+            thr = __uint_as_float(hq_rid[he] & ~1023u) * 1.00001f + 1.75e-4f +
+                  kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+#endif
         } else {
             ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
             is_live = mode == M_MARCH;
@@ -525,7 +530,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             const float ny = tap_t == 0u ? vy : tn[64u + lane] + vy;
             const float nz = tap_t == 0u ? vz : tn[128u + lane] + vz;
             if (++tap_t == 4u && !tagged) {
-                if (is_live) res[hq_rid[he]] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
+                if (is_live) res[hq_rid[he] & 1023u] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
                 tap_t = TAP_IDLE;
             } else {
                 tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
@@ -551,7 +556,13 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
             if (hit) {
                 const uint32_t e = hq_n + lane_rank(hit_mask);
+#ifdef RM_JIT_PRUNE_ON
+                // |sd| of the hit, rounded up to 22 bits, rides in the upper bits of the entry's ray id (< 1024): the
+                // pruning threshold of its normal taps ("Pruning"); a NaN stays a NaN (nothing is skipped then)
+                hq_rid[e] = rid | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);
+#else
                 hq_rid[e] = rid;
+#endif
                 hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
                 mode = M_EMPTY;
             }

@@ -192,14 +192,14 @@ def test_full_size_metric_config_specialised_vs_interpreter(res, oracle):
 
 
 def test_pruning_policy_by_primitive_count(oracle):
-    """RM_OPT_PRUNE = 2 (the default): the pruned form of the generated kernel for programs with at least 24 spheres +
-    boxes (G64: 32), the plain form below that (G32: 16); 0 / 1 force it; every form renders the oracle's image."""
+    """RM_OPT_PRUNE = 2 (the default): the pruned form of the generated kernel for programs with at least 12 spheres +
+    boxes (G32: 16, G64: 32), the plain form below that (G8: 4); 0 / 1 force it; every form renders the oracle's image."""
     W, H = 64, 40
     r = renderer.RayMarchingResources(0)
     try:
         r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
         r.set_limits(LIM)
-        for name, want in (("g32", {2: 0, 1: 1, 0: 0}), ("g64", {2: 1, 1: 1, 0: 0})):
+        for name, want in (("g8", {2: 0, 1: 1, 0: 0}), ("g32", {2: 1, 1: 1, 0: 0}), ("g64", {2: 1, 1: 1, 0: 0})):
             cc, w, u = case(oracle, ALL[name](), W, H)
             ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
             r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
