@@ -55,16 +55,16 @@ def frames_todo(out_dir, n_frames, rank, world, W, H, fmt):
 
 
 def write_frame(out_dir, f, img, fmt):
-    """img: (H, W, 4) uint8 in RGBA order, or float32 for fmt == 'f32'.  Atomic: temp file + rename."""
+    """img: (H, W, 3) or (H, W, 4) uint8 in RGB(A) order, or float32 RGBA for fmt == 'f32'.  Atomic: temp file + rename."""
     p = frame_path(out_dir, f, fmt)
     tmp = p + ".part"
     with open(tmp, "wb") as fh:
         if fmt == "f32":
-            fh.write(np.ascontiguousarray(img, dtype=np.float32).tobytes())
+            fh.write(memoryview(np.ascontiguousarray(img, dtype=np.float32)).cast("B"))
         else:
             H, W = img.shape[:2]
             fh.write(ppm_header(W, H))
-            fh.write(np.ascontiguousarray(img[..., :3]).tobytes())
+            fh.write(memoryview(np.ascontiguousarray(img[..., :3])).cast("B"))   # no copy when the image is already RGB
     os.replace(tmp, p)
     return p
 
@@ -121,7 +121,10 @@ def render_batch(args, rank=0, world=1, device=0, log=None):
     dt = torch.float32 if f32 else torch.uint8
     n_slots, n_writers = max(2, args.slots), max(1, args.writers)
     dev = [torch.empty((H, W, 4), dtype=dt, device="cuda") for _ in range(n_slots)]
-    host = [torch.empty((H, W, 4), dtype=dt).pin_memory() for _ in range(n_slots)]
+    # PPM holds RGB: the alpha plane is dropped on the device (a strided copy on the drain stream), so 3 B/px cross
+    # PCIe and the writer threads hand the pinned buffer to the file as it is
+    drain = dev if f32 else [torch.empty((H, W, 3), dtype=dt, device="cuda") for _ in range(n_slots)]
+    host = [torch.empty((H, W, 4 if f32 else 3), dtype=dt).pin_memory() for _ in range(n_slots)]
     render_s, copy_s = torch.cuda.Stream(), torch.cuda.Stream()
     rendered = [torch.cuda.Event() for _ in range(n_slots)]
     copied = [torch.cuda.Event() for _ in range(n_slots)]
@@ -160,7 +163,9 @@ def render_batch(args, rank=0, world=1, device=0, log=None):
         rendered[slot].record(render_s)
         copy_s.wait_event(rendered[slot])
         with torch.cuda.stream(copy_s):
-            host[slot].copy_(dev[slot], non_blocking=True)
+            if not f32:
+                drain[slot].copy_(dev[slot][..., :3])
+            host[slot].copy_(drain[slot], non_blocking=True)
         copied[slot].record(copy_s)
         jobs.put((f, slot))
         summary["frames_rendered"] += 1
