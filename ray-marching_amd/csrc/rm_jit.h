@@ -238,11 +238,140 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     return true;
 }
 
+// The four normal taps of a hit (wgsl:135-144) in one pass over the program: every record is applied to the four
+// positions c + k_t eps with the leaf functions and operators map_scene_spec uses, so each f[t] goes through the same
+// operations as a separate evaluation would -- but the compiler sees that the twelve coordinates take only six
+// different values, and one loop iteration replaces four.  With `prune` (bounded 1-Lipschitz leaves, min / max
+// operators), the far test of a sphere / box runs ONCE, at the hit position c, against a threshold the caller widened
+// by the tap offset eps sqrt(3): a leaf that passes it is far from all four taps and is skipped for all of them.
+// Returns false when the program contains a SmoothUnion (see below) or the records do not form a valid program: the
+// kernel then taps one position at a time through map_scene_spec.
+inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
+    std::string s;
+    char line[768];
+    s += "namespace rmk {\n";
+    s += "template <bool FAST>\n";
+    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, bool live, SqrtGuard& tiny, float (&f)[4]) {\n";
+    if (prune) {
+        s += "    const float thrk = thr * 1.000005f;\n";
+        s += "    const float thr2k = (thr * thr) * 1.00001f;\n";
+        s += "    const float inf = __uint_as_float(0x7F800000u);\n";
+    }
+    s += "    const float e = 0.0001f;\n";  // wgsl:136; k = (1,-1): taps (+,-,-), (-,-,+), (-,+,-), (+,+,+) (wgsl:138-141)
+    s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
+    s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
+    s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
+    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
+    int leaves = 0, nv = 0, np = 0;
+    std::vector<int> stack;
+    std::vector<int> pos;  // open transform scopes, as in generate_map_scene
+    pos.push_back(0);
+    for (size_t i = 0; i < rec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        const unsigned off = (unsigned)i * 8u + 1u;
+        if (kind == RM_KIND_XFORM) {
+            if (prune) return false;  // pruned programs have no transforms
+            const int c = pos.back();
+            if ((mode & 1u) == 0u) {
+                const int n = ++np;
+                for (int t = 0; t < 4; t++) {
+                    if (mode == RM_XF_T_PUSH)
+                        std::snprintf(line, sizeof line, "    const float x%d_%d = x%d_%d - lp[%u], y%d_%d = y%d_%d - lp[%u], z%d_%d = z%d_%d - lp[%u];\n",
+                                      n, t, c, t, off, n, t, c, t, off + 1u, n, t, c, t, off + 2u);
+                    else if (mode == RM_XF_R_PUSH)
+                        std::snprintf(line, sizeof line, "    float x%d_%d = x%d_%d, y%d_%d = y%d_%d, z%d_%d = z%d_%d; xf_rotate_conj(lp[%u], lp[%u], lp[%u], lp[%u], x%d_%d, y%d_%d, z%d_%d);\n",
+                                      n, t, c, t, n, t, c, t, n, t, c, t, off, off + 1u, off + 2u, off + 3u, n, t, n, t, n, t);
+                    else
+                        std::snprintf(line, sizeof line, "    const float x%d_%d = x%d_%d / lp[%u], y%d_%d = y%d_%d / lp[%u], z%d_%d = z%d_%d / lp[%u];\n",
+                                      n, t, c, t, off, n, t, c, t, off, n, t, c, t, off);
+                    s += line;
+                }
+                pos.push_back(n);
+            } else {
+                if (pos.size() < 2 || stack.empty()) return false;
+                pos.pop_back();
+                if (mode == RM_XF_S_POP) {
+                    const int a = stack.back(); stack.pop_back();
+                    const int w = nv++;
+                    for (int t = 0; t < 4; t++) {
+                        std::snprintf(line, sizeof line, "    const float v%d_%d = v%d_%d * lp[%u];\n", w, t, a, t, off);
+                        s += line;
+                    }
+                    stack.push_back(w);
+                }
+            }
+            continue;
+        }
+        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+            const int b = stack.back(); stack.pop_back();
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            // SmoothUnion: four copies of its division need ~130 VGPRs (3 waves per SIMD): 40 % slower than tapping one
+            // position at a time (measured); such programs keep the one-position taps
+            if (!op) return false;
+            for (int t = 0; t < 4; t++) {
+                std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, v%d_%d);\n", w, t, op, a, t, b, t);
+                s += line;
+            }
+            stack.push_back(w);
+            continue;
+        }
+        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
+                       : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
+        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
+        if (prune && kind == RM_KIND_PLANE) return false;
+        int a = -1;
+        if (mode != RM_MODE_PUSH) {
+            if (stack.empty()) return false;
+            a = stack.back(); stack.pop_back();
+        }
+        const int w = nv++;
+        const int c = pos.back();
+        const bool pruned = prune && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX);
+        if (pruned) {
+            for (int t = 0; t < 4; t++) {  // the value if the leaf is far: see generate_map_scene
+                if (mode == RM_MODE_PUSH || mode == RM_MODE_INTER) std::snprintf(line, sizeof line, "    float v%d_%d = inf;\n", w, t);
+                else std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d;\n", w, t, a, t);
+                s += line;
+            }
+            if (kind == RM_KIND_SPHERE)
+                std::snprintf(line, sizeof line, "    if (spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk))) {\n", off, off);
+            else
+                std::snprintf(line, sizeof line, "    if (spec_any_near(live, spec_box_a(lp + %u, cx, cy, cz).a > thr2k)) {\n", off);
+            s += line;
+        }
+        for (int t = 0; t < 4; t++) {
+            char leaf[192];
+            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x%d_%d, y%d_%d, z%d_%d)", fn, off, c, t, c, t, c, t);
+            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x%d_%d, y%d_%d, z%d_%d, tiny)", fn, off, c, t, c, t, c, t);
+            const char* decl = pruned ? "    " : "const float ";
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    %sv%d_%d = %s;\n", decl, w, t, leaf);
+            else std::snprintf(line, sizeof line, "    %sv%d_%d = %s(v%d_%d, %s);\n", decl, w, t, op, a, t, leaf);
+            s += line;
+        }
+        if (pruned) s += "    }\n";
+        stack.push_back(w);
+        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+    }
+    if (stack.empty()) return false;
+    for (int t = 0; t < 4; t++) {
+        std::snprintf(line, sizeof line, "    f[%d] = v%d_%d;\n", t, stack.back(), t);
+        s += line;
+    }
+    s += "}\n}  // namespace rmk\n";
+    *out = std::move(s);
+    return true;
+}
+
 inline const char* kernel_name() { return "rm_render_v5_spec"; }
 
 inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prune, bool materials, std::string* out) {
-    std::string body;
+    std::string body, taps;
     if (!generate_map_scene(rec, prune, &body)) return false;
+    const char* taps_knob = std::getenv("RM_JIT_TAPS4");  // A/B: RM_JIT_TAPS4=0 keeps the taps on map_scene_spec
+    const bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0) && generate_map_scene_taps(rec, prune, &taps);
     std::string s;
     // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
     s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
@@ -251,6 +380,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
          "#define int32_t rm_rtc_i32\n#define int64_t rm_rtc_i64\n";
     s += "#define RM_JIT_TU 1\n";
     if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
+    if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (const char* pr = std::getenv("RM_JIT_PRIO_LONG_RAYS")) {  // experiment knob
         s += "#define RM_PRIO_LONG_RAYS ";
         s += std::to_string(std::atoi(pr));
@@ -258,6 +388,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     }
     s += "#include \"rm_kernel_v5.h\"\n";
     s += body;
+    if (taps4) s += taps;
     char line[512];
     if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) {  // experiment knob: cap the VGPR budget
         std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", std::atoi(w), std::atoi(w));

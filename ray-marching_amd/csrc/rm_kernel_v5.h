@@ -47,6 +47,11 @@ RM_DEV LdsF lds_vector_base(const void* generic_lds_ptr) {
 }
 template <bool FAST>
 RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval);
+#ifdef RM_JIT_TAPS4
+// The four normal taps of a hit at c in one pass (rm_jit.h generate_map_scene_taps): f[t] = map_scene(c + k_t eps).
+template <bool FAST>
+RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, bool live, SqrtGuard& tiny, float (&f)[4]);
+#endif
 
 // ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
 // A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
@@ -486,6 +491,35 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             }
         }
 
+#ifdef RM_JIT_TAPS4
+        if (tapping) {  // all four normal taps of the batch in one pass over the program (wgsl:135-144)
+            const uint32_t e = hq_n + lane;
+            const float cx = hq_v[e], cy = hq_v[V5_HQ + e], cz = hq_v[2u * V5_HQ + e];
+            const bool live4 = lane < tap_n;
+            // |F(tap)| <= |sd_hit| + eps sqrt(3) + error: the threshold of a tap ("Pruning"); the far test runs at c,
+            // another eps sqrt(3) and one more leaf-evaluation error away from every tap
+            const float m = kPruneAbs * (prune_scale + (((__builtin_fabsf(cx) + __builtin_fabsf(cy)) + __builtin_fabsf(cz)) + 1.0e-3f));
+            const float thr_c = __uint_as_float(hq_rid[e] & ~1023u) * 1.00001f + 3.5e-4f + (m + m);
+            float f[4];
+            SqrtGuard tiny;
+            map_scene_taps<true>(lprog_v, cx, cy, cz, thr_c, live4, tiny, f);
+            if (__ballot(tiny.bad()) != 0ull) map_scene_taps<false>(lprog_v, cx, cy, cz, thr_c, live4, tiny, f);
+            n_iter++;
+            n_live += (uint32_t)__popcll(__ballot(live4));
+            // n = ((k0 f0 + k1 f1) + k2 f2) + k3 f3, k = (+,-,-), (-,-,+), (-,+,-), (+,+,+); products with +-1 are exact
+            const float nx = ((f[0] + -f[1]) + -f[2]) + f[3];
+            const float ny = ((-f[0] + -f[1]) + f[2]) + f[3];
+            const float nz = ((-f[0] + f[1]) + -f[2]) + f[3];
+            if (tagged) {
+                tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
+                tap_t = 4u;  // the material phase follows
+            } else {
+                if (live4) res[hq_rid[e] & 1023u] = shade_hit(nx, ny, nz, cx, cy, cz);  // wgsl:98-103
+                tap_t = TAP_IDLE;
+            }
+            continue;
+        }
+#endif
         // ---- B. one map_scene evaluation: a march step of every live ray, or normal tap tap_t of every waiting hit ----
         float ex, ey, ez, thr = inf_f;
         bool is_live;
