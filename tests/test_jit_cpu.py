@@ -205,3 +205,41 @@ def test_disk_cache_of_compiled_kernels(oracle, tmp_path):
     (tmp_path / files[0]).write_bytes(b"not a code object")
     assert run("g8")[2] == "compiled"                      # a damaged entry is ignored and replaced
     assert (tmp_path / files[0]).read_bytes()[:4] == b"\x7fELF"
+
+
+def test_four_taps_in_one_pass_function(oracle):
+    """Generated kernels take the four normal taps of a hit (wgsl:135-144) in one pass: every record applied to the four
+    positions c + k_t eps, in the pruned form behind ONE far test at the hit position.  Programs with a SmoothUnion
+    keep the one-position taps (four copies of its division cost too many registers)."""
+    def taps_body(src):
+        m = re.search(r"void map_scene_taps\(.*?\) \{\n(.*?)\n\}\n\}", src, re.S)
+        assert m, src[-1500:]
+        return [l.strip() for l in m.group(1).splitlines()]
+
+    cc, w = serialize(oracle, scenes.g8())     # ((S u B) - S) u B
+    src = renderer.jit_source(cc, w)
+    assert "#define RM_JIT_TAPS4 1" in src
+    body = taps_body(src)
+    assert body[:4] == ["const float e = 0.0001f;",
+                        "const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;",
+                        "const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;",
+                        "const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;"]
+    assert body[4:8] == ["const float v0_%d = spec_sphere<FAST>(lp + 1, x0_%d, y0_%d, z0_%d, tiny);" % (t, t, t, t) for t in range(4)]
+    assert body[8:12] == ["const float v1_%d = vmin(v0_%d, spec_box<FAST>(lp + 9, x0_%d, y0_%d, z0_%d, tiny));" % (t, t, t, t, t) for t in range(4)]
+    assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
+    pruned = taps_body(renderer.jit_source(cc, w, prune=True))
+    k = pruned.index("float v0_0 = inf;")
+    assert pruned[k:k + 10] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
+                                "if (spec_any_near(live, spec_sphere_far(lp + 1, spec_sphere_a(lp + 1, cx, cy, cz), thrk))) {",
+                                "v0_0 = spec_sphere<FAST>(lp + 1, x0_0, y0_0, z0_0, tiny);",
+                                "v0_1 = spec_sphere<FAST>(lp + 1, x0_1, y0_1, z0_1, tiny);",
+                                "v0_2 = spec_sphere<FAST>(lp + 1, x0_2, y0_2, z0_2, tiny);",
+                                "v0_3 = spec_sphere<FAST>(lp + 1, x0_3, y0_3, z0_3, tiny);", "}"]
+    # transforms: every scope gets four positions; smooth unions: no four-tap function
+    cc, w = serialize(oracle, scenes.xform_mix())
+    src = renderer.jit_source(cc, w)
+    assert "#define RM_JIT_TAPS4 1" in src and "x1_3" in "\n".join(taps_body(src))
+    for scene in (scenes.g32s(), scenes.ext_mix()):
+        cc, w = serialize(oracle, scene)
+        src = renderer.jit_source(cc, w)
+        assert "RM_JIT_TAPS4" not in src and "map_scene_taps(" not in src.split('#include "rm_kernel_v5.h"')[1]
