@@ -167,11 +167,14 @@ int ensure_program(rm_ctx* c, hipStream_t s) {
         c->cmd_status = rc;
         return fail(c, rc, "invalid CSG program in command buffer: %s", rm_status_string(rc));
     }
-    if (d.rec.size() > c->d_prog_cap) {
+    // the group records of a prunable program (RmDecoded::groups) follow its records in the same buffer
+    std::vector<RmRecord> image = d.rec;
+    image.insert(image.end(), d.groups.begin(), d.groups.end());
+    if (image.size() > c->d_prog_cap) {
         if (c->d_prog) (void)hipFree(c->d_prog);
         c->d_prog = nullptr;
         c->d_prog_cap = 0;
-        size_t cap = std::max<size_t>(64, d.rec.size() * 2);
+        size_t cap = std::max<size_t>(64, image.size() * 2);
         hipError_t e = hipMalloc(&c->d_prog, cap * sizeof(RmRecord));
         if (e != hipSuccess) {
             c->cmd_dirty = true;
@@ -179,8 +182,8 @@ int ensure_program(rm_ctx* c, hipStream_t s) {
         }
         c->d_prog_cap = cap;
     }
-    if (!d.rec.empty()) {
-        if (int urc = upload(c, c->d_prog, d.rec.data(), d.rec.size() * sizeof(RmRecord), s)) {
+    if (!image.empty()) {
+        if (int urc = upload(c, c->d_prog, image.data(), image.size() * sizeof(RmRecord), s)) {
             c->cmd_dirty = true;
             return urc;
         }
@@ -375,7 +378,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (L.n_mrec != 0u) L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
     const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
-                         (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms) +
+                         (lds ? (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms) +
                          (L.n_mrec != 0u ? 1024u : 0u);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
@@ -432,7 +435,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
     int wpt = c->waves_per_tile;
-    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + 16u + (L.n_mrec != 0u ? 1024u : 0u);
+    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + (lds ? (size_t)L.n_grp * sizeof(RmRecord) : 0u) +
+                         16u + (L.n_mrec != 0u ? 1024u : 0u);
     const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
     while (wpt > 1 && fixed + (size_t)wpt * (rmk::V5_WAVE_DWORDS * 4u + depth * 256u) > 48u * 1024u)
         wpt /= 2;
@@ -473,6 +477,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.strip_rows = strips.rows; L.strip_first = strips.first; L.strip_stride = strips.stride;
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
+    L.n_grp = (uint32_t)c->decoded.groups.size();
     L.value_spill_depth = c->decoded.spill_depth;
     L.spill_depth = c->decoded.spill_depth + 3u * c->decoded.xform_depth;  // saved positions follow the value stack
     L.bounds = c->decoded.has_xforms ? c->d_bounds : nullptr;

@@ -33,6 +33,16 @@ struct RmDecoded {
     // 1-Lipschitz leaf or a min/max operator; scene_scale = 1 + max over primitives of |centre|_1 + |size|_1
     bool prunable = true;
     float scene_scale = 1.0f;
+    // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
+    // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
+    // on the structure only -- the generated code is compiled per structure -- the spheres on the parameters:
+    // p[0..2] centre, p[3] radius R', p[4] = R' * 1.000005 rounded up (what spec_sphere_far reads), where
+    //   R' = (R + 2e-6 (|c|_1 + R)) (1 + 1e-6),  R = max_i (|c_i - c| + rho_i)   (rho: radius / half-diagonal)
+    // covers a member's own evaluation error: a member's value at p is >= |p - c| - R in real arithmetic (triangle
+    // inequality; a box's distance is at least the distance to its bounding sphere), and its computed value differs
+    // from that by at most ~4e-7 of |p|_1 + |c_i|_1 + rho_i -- near the group, where the test matters, that is within
+    // the 2e-6 (|c|_1 + R) added here plus the factor 1.000005 applied to thr + R' by the test.
+    std::vector<RmRecord> groups;
     // Space transformations (extension): deepest nesting, and -- because a transformed primitive's parameters no longer
     // say where it is -- one world-space bounding sphere (x, y, z, radius) per bounded primitive for the miss tests.
     // cull_veto: some transform is not a similarity (non-unit quaternion, scale not positive and finite): no culling.
@@ -243,6 +253,35 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
     }
     if (!scopes.empty()) return RM_ERR_TRANSFORM;
     if (cmd_count && depth < 1) return RM_ERR_EMPTY_RESULT;
+    if (d.prunable) {  // group spheres, see RmDecoded::groups
+        const RmRecord* first = nullptr;
+        for (const RmRecord& r : d.rec) {
+            const uint32_t kind = RM_OP_KIND(r.op);
+            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) continue;
+            if (!first) { first = &r; continue; }
+            const RmRecord* m[2] = {first, &r};
+            double c[3], R = 0.0;
+            for (int k = 0; k < 3; k++) c[k] = 0.5 * ((double)m[0]->p[k] + (double)m[1]->p[k]);
+            for (int i = 0; i < 2; i++) {
+                const RmRecord& q = *m[i];
+                const double rho = RM_OP_KIND(q.op) == RM_KIND_SPHERE ? std::fmax((double)q.p[3], 0.0)
+                                 : std::sqrt(std::pow(std::fmax((double)q.p[3], 0.0), 2) + std::pow(std::fmax((double)q.p[4], 0.0), 2) +
+                                             std::pow(std::fmax((double)q.p[5], 0.0), 2));
+                const double dist = std::sqrt(std::pow(q.p[0] - c[0], 2) + std::pow(q.p[1] - c[1], 2) + std::pow(q.p[2] - c[2], 2)) + rho;
+                R = dist > R || dist != dist ? dist : R;  // a NaN sticks: the group is then never far
+            }
+            R = (R + 2.0e-6 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + R)) * (1.0 + 1.0e-6);
+            RmRecord g;
+            std::memset(&g, 0, sizeof g);
+            g.op = RM_OP(RM_KIND_SPHERE, RM_MODE_PUSH, 0);
+            // the centre is rounded to binary32: its displacement (<= an ulp of |c|) is inside the 2e-6 |c|_1 slack
+            g.p[0] = (float)c[0]; g.p[1] = (float)c[1]; g.p[2] = (float)c[2];
+            g.p[3] = std::nextafterf((float)R, INFINITY);
+            g.p[4] = std::nextafterf((float)((double)g.p[3] * 1.000005), INFINITY);
+            d.groups.push_back(g);
+            first = nullptr;
+        }
+    }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     d.n_words = ptr;
     *out = std::move(d);

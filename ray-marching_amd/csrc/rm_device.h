@@ -56,6 +56,9 @@ enum : uint32_t { RM_CMD_MATERIAL = 300, RM_MAX_MATERIALS = 256 };
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
     uint32_t n_rec;            // == cmd_count of the reference program
+    uint32_t n_grp;            // group records that follow the n_rec program records in `prog` (far-primitive pruning: one
+                               // bounding sphere per pair of consecutive sphere / box leaves, RmDecoded::groups); staged in
+                               // LDS with the program
     uint32_t spill_depth;      // LDS slots per lane this program needs: value stack, then 3 per transform level
     uint32_t value_spill_depth; // the value-stack part of spill_depth (saved positions start at this slot)
     const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:

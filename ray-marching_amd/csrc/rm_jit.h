@@ -140,11 +140,21 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     // (RM_JIT_SCHED_BARRIER=N overrides, 0 disables.)
     const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
     int leaves = 0;
+    // Grouped far tests: consecutive sphere / box leaves pair up (RmDecoded::groups: pair g = pruned leaves 2g, 2g + 1;
+    // its bounding sphere is record n_rec + g of the LDS copy); one test clears both members.
+    int n_pruned_total = 0, n_pruned = 0;
+    for (const RmRecord& r : rec) n_pruned_total += prune && (RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX);
     std::vector<int> stack;  // value numbers; back() is the accumulator
     std::vector<int> pos;    // position numbers of the open transform scopes; back() is the current one (0 = qx, qy, qz)
     int nv = 0, np = 0;
     s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
     pos.push_back(0);
+    // all group tests up front: their LDS reads go out together instead of one stalling in front of every pair
+    for (int g = 0; 2 * g + 1 < n_pruned_total; g++) {
+        const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u + 1u;
+        std::snprintf(line, sizeof line, "    const bool g%d = spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, x0, y0, z0), thrk));\n", g, goff, goff);
+        s += line;
+    }
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
         const unsigned off = (unsigned)i * 8u + 1u;  // first parameter of record i, in dwords
@@ -206,6 +216,11 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
             else std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
             s += line;
             char leaf[128];
+            const int ordinal = n_pruned++, grp = ordinal / 2;
+            if ((ordinal | 1) < n_pruned_total) {  // this leaf has a partner
+                std::snprintf(line, sizeof line, "    if (g%d)\n", grp);
+                s += line;
+            }
             if (kind == RM_KIND_SPHERE) {
                 std::snprintf(line, sizeof line, "    { const float a = spec_sphere_a(lp + %u, %s);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", off, P, off);
                 std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
@@ -261,8 +276,19 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
     s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
     s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
     s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
+    if (prune) {  // group tests up front, as in generate_map_scene
+        int total = 0;
+        for (const RmRecord& r : rec) total += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
+        for (int g = 0; 2 * g + 1 < total; g++) {
+            const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u + 1u;
+            std::snprintf(line, sizeof line, "    const bool g%d = spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk));\n", g, goff, goff);
+            s += line;
+        }
+    }
     const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
     int leaves = 0, nv = 0, np = 0;
+    int n_pruned_total = 0, n_pruned = 0;  // grouped far tests, as in generate_map_scene
+    for (const RmRecord& r : rec) n_pruned_total += prune && (RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX);
     std::vector<int> stack;
     std::vector<int> pos;  // open transform scopes, as in generate_map_scene
     pos.push_back(0);
@@ -336,10 +362,17 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
                 else std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d;\n", w, t, a, t);
                 s += line;
             }
+            const int ordinal = n_pruned++, grp = ordinal / 2;
+            const char* guard = "";
+            char gname[32];
+            if ((ordinal | 1) < n_pruned_total) {
+                std::snprintf(gname, sizeof gname, "g%d && ", grp);
+                guard = gname;
+            }
             if (kind == RM_KIND_SPHERE)
-                std::snprintf(line, sizeof line, "    if (spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk))) {\n", off, off);
+                std::snprintf(line, sizeof line, "    if (%sspec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk))) {\n", guard, off, off);
             else
-                std::snprintf(line, sizeof line, "    if (spec_any_near(live, spec_box_a(lp + %u, cx, cy, cz).a > thr2k)) {\n", off);
+                std::snprintf(line, sizeof line, "    if (%sspec_any_near(live, spec_box_a(lp + %u, cx, cy, cz).a > thr2k)) {\n", guard, off);
             s += line;
         }
         for (int t = 0; t < 4; t++) {

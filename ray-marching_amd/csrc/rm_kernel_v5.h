@@ -302,7 +302,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
     float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
     uint32_t* lprog = reinterpret_cast<uint32_t*>(t_slab + 3u * L.n_slab);
-    uint32_t* s_next = lprog + (PROG_IN_LDS ? L.n_rec * 8u : 0u);      // shared pool cursor
+    uint32_t* s_next = lprog + (PROG_IN_LDS ? (L.n_rec + L.n_grp) * 8u : 0u);  // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
     uint32_t* s_veto = s_next + 2;
     uint8_t* rmat = reinterpret_cast<uint8_t*>(s_next + 4);            // MAT, tagged program: [1024] material per ray
@@ -322,7 +322,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float eps = 0.0001f;                                    // wgsl:136
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
-        for (uint32_t k = tid; k < L.n_rec * 8u; k += 64u * WPT) lprog[k] = src[k];
+        for (uint32_t k = tid; k < (L.n_rec + L.n_grp) * 8u; k += 64u * WPT) lprog[k] = src[k];  // program, then group records
     }
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();

@@ -214,3 +214,45 @@ def test_pruning_policy_by_primitive_count(oracle):
             r.set_option(_ffi.RM_OPT_PRUNE, 3)
     finally:
         r.close()
+
+
+def test_grouped_far_tests_far_from_the_origin_and_with_distant_partners(oracle):
+    """The pruned form tests pairs of consecutive sphere / box leaves against a bounding sphere first (rm_decode.h:
+    RmDecoded::groups).  Scenes that stress the bound: everything 1000 units from the origin (the members' own
+    evaluation error is then ~1e-4), partners far apart (a huge group sphere), partners that coincide, degenerate radii,
+    an odd number of leaves; and the same kernel after the parameters moved (group spheres follow the upload)."""
+    rng = np.random.default_rng(77)
+    W, H = 64, 40
+    lim = (0.01, 100.0, 80)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        r.set_limits(lim)
+        r.resize_command_buffer(4096)
+        for offset in ((0.0, 0.0, 0.0), (800.0, -300.0, 500.0)):
+            for variant in range(4):
+                t = scenes._Tab()
+                leaves = []
+                for k in range(13):
+                    c = rng.uniform(-1.8, 1.8, 3) + np.array(offset)
+                    if variant == 1 and k % 2 == 1:
+                        c = c + rng.uniform(-40.0, 40.0, 3)            # the partner is far away
+                    if variant == 2 and k % 2 == 1:
+                        c = np.array(t.nodes[leaves[-1]][1][:3])        # the partner sits at the same place
+                    if rng.random() < 0.5:
+                        leaves.append(t.sphere(tuple(c), float(rng.choice([rng.uniform(0.2, 0.7), 0.0, -0.2], p=[0.8, 0.1, 0.1]))))
+                    else:
+                        leaves.append(t.box(tuple(c), tuple(rng.uniform(0.1, 0.6, 3))))
+                acc = leaves[0]
+                for k, leaf in enumerate(leaves[1:]):
+                    acc = t.op(scenes.SUBTRACTION if k % 5 == 4 else scenes.INTERSECTION if variant == 3 and k % 4 == 1 else scenes.UNION, acc, leaf)
+                cc, w = oracle.serialize(t.nodes, acc)
+                for events in (scenes.STILL_CAMERA_EVENTS, [(1, 140.0, 40.0), (2, -30.0, 0.0)]):
+                    u, *_ = oracle.orbit_uniforms((float(W), float(H)), target=offset, events=events)
+                    r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+                    r.set_program(cc, w)
+                    assert r.draw(W, H).tobytes() == oracle.render(u, lim, cc, w, W, H, threads=4).tobytes(), (offset, variant, events)
+                    assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 1
+    finally:
+        r.close()

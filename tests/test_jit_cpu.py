@@ -38,16 +38,23 @@ def test_generated_code_follows_the_postfix_program(oracle):
     assert body[:4] == ["const float thrk = thr * 1.000005f;", "const float thr2k = (thr * thr) * 1.00001f;",
                         "const float inf = __uint_as_float(0x7F800000u);", "const float x0 = qx, y0 = qy, z0 = qz;"]
     assert body[4:] == [
+        # consecutive sphere / box leaves share a bounding-sphere test: group record g follows the 4 program records
+        "const bool g0 = spec_any_near(live, spec_sphere_far(lp + 33, spec_sphere_a(lp + 33, x0, y0, z0), thrk));",
+        "const bool g1 = spec_any_near(live, spec_sphere_far(lp + 41, spec_sphere_a(lp + 41, x0, y0, z0), thrk));",
         "float v0 = inf;",
+        "if (g0)",
         "{ const float a = spec_sphere_a(lp + 1, x0, y0, z0);",
         "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); } }",
         "float v1 = v0;",
+        "if (g0)",
         "{ const SpecBox b = spec_box_a(lp + 9, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
+        "if (g1)",
         "{ const float a = spec_sphere_a(lp + 17, x0, y0, z0);",
         "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); } }",
         "float v3 = v2;",
+        "if (g1)",
         "{ const SpecBox b = spec_box_a(lp + 25, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
         "__builtin_amdgcn_sched_barrier(0);",
@@ -76,6 +83,9 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
         line = line.strip()
         if line.startswith(("const float thr", "const float inf", "const float x0", "__builtin_amdgcn_sched_barrier")):
             continue
+        if re.match(r"const bool g\d+ = spec_any_near\(live, spec_sphere_far\(lp \+ \d+, spec_sphere_a\(lp \+ \d+, x0, y0, z0\), thrk\)\);$", line) \
+                or re.match(r"if \(g\d+\)$", line):
+            continue      # group tests: a group that is far implies each member is (tests/test_gpu_* check the spheres)
         if line.startswith("return"):
             return env[line.rstrip(";").split()[1]]
         m = re.match(r"float (v\d+) = (\w+);", line)
@@ -229,8 +239,10 @@ def test_four_taps_in_one_pass_function(oracle):
     assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
     pruned = taps_body(renderer.jit_source(cc, w, prune=True))
     k = pruned.index("float v0_0 = inf;")
+    assert pruned[k - 2:k] == ["const bool g0 = spec_any_near(live, spec_sphere_far(lp + 33, spec_sphere_a(lp + 33, cx, cy, cz), thrk));",
+                               "const bool g1 = spec_any_near(live, spec_sphere_far(lp + 41, spec_sphere_a(lp + 41, cx, cy, cz), thrk));"]
     assert pruned[k:k + 10] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
-                                "if (spec_any_near(live, spec_sphere_far(lp + 1, spec_sphere_a(lp + 1, cx, cy, cz), thrk))) {",
+                                "if (g0 && spec_any_near(live, spec_sphere_far(lp + 1, spec_sphere_a(lp + 1, cx, cy, cz), thrk))) {",
                                 "v0_0 = spec_sphere<FAST>(lp + 1, x0_0, y0_0, z0_0, tiny);",
                                 "v0_1 = spec_sphere<FAST>(lp + 1, x0_1, y0_1, z0_1, tiny);",
                                 "v0_2 = spec_sphere<FAST>(lp + 1, x0_2, y0_2, z0_2, tiny);",
