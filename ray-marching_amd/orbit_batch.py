@@ -194,6 +194,7 @@ def parse(argv=None):
     p.add_argument("--format", choices=["ppm", "f32"], default="ppm", help="ppm: 8-bit output stage; f32: raw RGBA32F")
     p.add_argument("--slots", type=int, default=4, help="device / pinned-host buffer pairs in flight")
     p.add_argument("--writers", type=int, default=3, help="file-writer threads")
+    p.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0")
     return p.parse_args(argv)
 
 
@@ -202,7 +203,7 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    s = render_batch(args, rank, world, local_rank, log=lambda m: print(m, flush=True))
+    s = render_batch(args, rank, world, 0 if args.all_ranks_on_device0 else local_rank, log=lambda m: print(m, flush=True))
     s["Mpixels_per_s"] = s["frames_rendered"] * args.width * args.height / s["seconds"] / 1e6 if s["seconds"] else 0.0
     s["frames_per_s"] = s["frames_rendered"] / s["seconds"] if s["seconds"] else 0.0
     s["config"] = "%d frames %dx%d %s %d steps, format %s, frame f -> rank f %% %d" % (
