@@ -1,13 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- Mpixels/s of the SDF ray-marching hot path on MI355X.
 
-A step = one full frame (prepare's uniform write + the draw) of the BASELINE metric
-workload: 1920x1080, 32-node graph (G32), 256 max steps, still orbit camera of SURVEY 8(d).
-The output image stays resident in HBM.  N > 1 (launched by torch.distributed.run, one rank
-per GPU): frames are sharded over ranks with no data-path collective ("weak" scaling: every
-rank renders its own K frames); only the timing barrier / max-over-ranks uses the process group.
+A step = one frame of the BASELINE metric workload as the reference's RayMarchingCallback issues it
+(renderer.rs:196-255): prepare (uniform write + command-buffer rewrite) and paint (the draw) --
+1920x1080, 32-node graph (G32), 256 max steps, still orbit camera of SURVEY 8(d).  The image stays
+resident in HBM for `value`; the PCIe-inclusive rate of the same frames is reported beside it
+(`end_to_end`), never as `value`.
 
-Prints ONE JSON line on rank 0.
+  --gpus 1   whole frames on one GPU, four frames in flight (one context / stream / image each).
+  --gpus N   north-star layout: every frame is tiled over the N GPUs in interleaved 16-row strips
+             (rm_draw_strips), one process per GPU, no collective on the data path; `value` counts
+             whole frames with each GPU's strips resident in its HBM, `end_to_end` adds the final
+             host-side gather (rm_gather_strips: every rank copies its strips into one shared-memory
+             frame; the only inter-process traffic is a completion counter), and `frames_sharded` is
+             the other partition (whole frames per rank: BASELINE config 5's, selected as the
+             headline by --camera orbit).
+
+`python bench.py --gpus N` starts its own N rank processes (before anything touches the GPU) unless
+it already runs under a launcher (WORLD_SIZE set, e.g. torch.distributed.run).  Rank 0 prints ONE
+JSON line.
 """
 import argparse
 import json
@@ -21,9 +32,10 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # ditto
 BYTES_PER_PIXEL = 16             # one RGBA32F store per pixel: SURVEY 8(d) algorithmic bytes
+VALU_CYCLES_PER_WAVE_INST = 2.0  # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200)
@@ -33,8 +45,8 @@ def parse():
     p.add_argument("--scene", default="g32")
     p.add_argument("--max-iter", type=int, default=256)
     p.add_argument("--kernel", type=int, default=0, help="rm_kernel enum (0 = default tuned kernel)")
-    p.add_argument("--refill-min", type=int, default=0, help="raypool refill threshold (0 = library default)")
-    p.add_argument("--waves-per-tile", type=int, default=0, help="v3 kernels: 1/2/4/8 waves share a tile (0 = default)")
+    p.add_argument("--refill-min", type=int, default=0, help="idle lanes that trigger a refill (0 = library default)")
+    p.add_argument("--waves-per-tile", type=int, default=0, help="1/2/4/8 waves share a tile (0 = default)")
     p.add_argument("--specialize", type=int, default=2, choices=[0, 1, 2],
                    help="structure specialisation of the march kernel (hipRTC): 0 interpreter kernel only, 1 compile in the "
                         "background, 2 compile when the scene is uploaded (default: the scene is static, so the one-off "
@@ -43,24 +55,24 @@ def parse():
                    help="far-primitive pruning in the specialised kernel (exact): 0 off, 1 on, 2 for programs with >= 12 primitives; "
                         "-1 (default) leaves the library default (2)")
     p.add_argument("--no-cull", action="store_true", help="A/B: disable the exact miss-ray culling")
-    p.add_argument("--no-balance", action="store_true", help="A/B: disable the heaviest-tile-first pre-pass")
-    p.add_argument("--balance", type=int, default=-1, help="A/B: RM_OPT_BALANCE value (0 raster, 1 fullest tiles first, 2 silhouette tiles first)")
-    p.add_argument("--camera", choices=["still", "orbit"], default="still")
-    p.add_argument("--mode", choices=["frames", "tile"], default="frames",
-                   help="frames: every rank renders whole frames (weak scaling, default); tile: ONE frame per step "
-                        "is tiled over the ranks in interleaved 16-row strips (strong scaling, north-star layout)")
+    p.add_argument("--balance", type=int, default=-1, help="A/B: RM_OPT_BALANCE value (0 raster ... 3 last frame's durations)")
+    p.add_argument("--camera", choices=["still", "orbit"], default="still",
+                   help="still: the metric's camera; orbit: frame f of a 1024-frame orbit (BASELINE config 5)")
+    p.add_argument("--mode", choices=["auto", "frames", "tile"], default="auto",
+                   help="tile: every frame is tiled over the ranks in interleaved 16-row strips (north-star layout; auto for "
+                        "--gpus > 1 with the still camera); frames: every rank renders whole frames (auto for one GPU and for "
+                        "the orbit batch)")
     p.add_argument("--dist-backend", default="nccl", help="process-group backend for the timing barrier (nccl = RCCL)")
     p.add_argument("--all-ranks-on-device0", action="store_true",
                    help="rehearsal on a one-GPU box: every rank uses GPU 0 (use with --dist-backend gloo)")
-    p.add_argument("--gather", nargs="?", const="gloo", default=None, choices=["gloo", "shm"],
-                   help="tile mode: include the host-side gather in the timed region: gloo = gather to rank 0 over the "
-                        "process group; shm = every rank copies its strips into one shared-memory image (never RCCL)")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-ab", action="store_true", help="skip the serial and interpreter-kernel legs that follow the timed region")
+    p.add_argument("--no-legs", "--no-ab", dest="no_legs", action="store_true",
+                   help="only the headline measurement (skips the serial / orbit / interpreter / end-to-end legs)")
     p.add_argument("--frames-in-flight", type=int, default=4,
                    help="frames drawn concurrently, each on its own context / stream / output buffer (1 = strictly serial)")
     p.add_argument("--cpu-sample-div", type=int, default=1, help="CPU baseline renders W/div x H/div")
-    return p.parse_args()
+    p.add_argument("--launch-timeout", type=float, default=900.0, help="--gpus N self-launch: seconds before the ranks are stopped")
+    return p.parse_args(argv)
 
 
 def host_cores():
@@ -74,6 +86,21 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return n
+
+
+def launch_ranks(args, argv):
+    """--gpus N without a launcher: start the N ranks ourselves.  This process never initialises the GPU."""
+    from ray_marching_amd import launch
+    rc, out = launch.run_ranks(args.gpus, launch.python_argv(os.path.abspath(__file__), argv), timeout=args.launch_timeout)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    elif out.strip():
+        sys.stderr.write(out)
+    if rc == 0 and not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        rc = 1
+    return rc
 
 
 def cpu_baseline(args, scene_words, cam_events):
@@ -96,15 +123,16 @@ def cpu_baseline(args, scene_words, cam_events):
             "label": "CPU restatement of the reference shader (oracle/rm_oracle.c), not wgpu"}, cnt, (W, H)
 
 
-def main():
-    args = parse()
+def run_rank(args):
     import torch
     import torch.distributed as dist
-    from ray_marching_amd import _ffi, camera, csg, renderer
+    from ray_marching_amd import _ffi, camera, csg, renderer, shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -112,21 +140,24 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     if args.all_ranks_on_device0:
         local_rank = 0
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants GPU %d, %d visible (one-GPU rehearsal: --all-ranks-on-device0 "
+                         "--dist-backend gloo)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     if world > 1:
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=args.dist_backend)
-    assert args.gpus == world, "--gpus %d but WORLD_SIZE=%d" % (args.gpus, world)
+    red_device = "cuda" if (world > 1 and args.dist_backend == "nccl") else "cpu"
 
-    W, H = args.width, args.height
-    from ray_marching_amd import shard
-    tile = args.mode == "tile"
-    # Frames in flight: frame f is drawn by context f % F on stream f % F into buffer f % F (a renderer with F frames in flight).
-    # A frame's draw ends with a tail in which its last tiles drain and most of the chip idles; the next frame's
-    # launches fill it.  F = 1 is the strictly serial loop.  (Tile mode gathers every frame: serial by nature.)
-    F = 1 if tile else max(1, args.frames_in_flight)
+    W, H, K = args.width, args.height, args.steps
+    mode = args.mode
+    if mode == "auto":
+        mode = "tile" if (world > 1 and args.camera == "still") else "frames"
+    tile = mode == "tile"
+    F = max(1, args.frames_in_flight)
+    SR = shard.DEFAULT_STRIP_ROWS
     node = csg.scene(args.scene)
     cc, words = csg.serialize(node)
 
@@ -144,8 +175,6 @@ def main():
             r.set_option(_ffi.RM_OPT_CULL, 0)
         if args.balance >= 0:
             r.set_option(_ffi.RM_OPT_BALANCE, args.balance)
-        if args.no_balance:
-            r.set_option(_ffi.RM_OPT_BALANCE, 0)
         r.set_limits(renderer.RayMarchLimits(0.01, 100.0, args.max_iter))
         if len(words) > 255:
             r.resize_command_buffer(4 * (len(words) + 1 + 63) // 64 * 64)
@@ -154,162 +183,232 @@ def main():
 
     ctxs = [make_context() for _ in range(F)]
     res = ctxs[0]
-
-    still_events = [(1, 35.0, -25.0)]                      # Orbit([35,-25]): yaw 0.35, pitch -0.25
-    ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
-    ctl.update(camera.Orbit([35.0, -25.0]))
-
-    def uniforms_for(step):
-        if args.camera == "orbit":                          # config 5: frame f of a 1024-frame orbit
-            f = (step * world + rank) % 1024
-            ctl.set_angles(2.0 * 3.141592653589793 * f / 1024.0, -0.25, 5.0)
-        return renderer.prepare_uniforms((float(W), float(H)), ctl.camera())
-
-    my_rows = shard.strip_row_count(H, shard.DEFAULT_STRIP_ROWS, rank, world) if tile else H
-    outs = [torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda") for _ in range(F)]
-    out = outs[0]
-    gloo = dist.new_group(backend="gloo") if (tile and args.gather and world > 1) else None
-    shared = pinned = None
-    if tile and args.gather == "shm":
-        def host_barrier():
-            dist.barrier(group=gloo)
-        shared = shard.SharedImage("rm_bench_%s" % os.environ.get("MASTER_PORT", "0"), W, H).open(
-            rank, world, host_barrier if world > 1 else (lambda: None))
-        pinned = torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32).pin_memory()
     streams = [torch.cuda.Stream() for _ in range(F)]   # kernels, events and syncs of frame f all use stream f % F
-    stream = streams[0]
-    torch.cuda.set_stream(stream)
-    sptr = stream.cuda_stream
+    torch.cuda.set_stream(streams[0])
+
+    still_events = [(1, 35.0, -25.0)]                      # Orbit([35,-25]): yaw 0.35, pitch -0.25 (SURVEY 8(d))
+    still_ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
+    still_ctl.update(camera.Orbit([35.0, -25.0]))
+    orbit_ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
+
+    def uniforms(step, cam, frame_stride=1, frame_offset=0):
+        if cam == "orbit":                                  # config 5: frame f of a 1024-frame orbit
+            f = (step * frame_stride + frame_offset) % 1024
+            orbit_ctl.set_angles(2.0 * 3.141592653589793 * f / 1024.0, -0.25, 5.0)
+            return renderer.prepare_uniforms((float(W), float(H)), orbit_ctl.camera())
+        return renderer.prepare_uniforms((float(W), float(H)), still_ctl.camera())
+
+    total = args.warmup + K
+    my_rows = shard.strip_row_count(H, SR, rank, world)
+    full = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(F)]          # whole frames
+    strips = [torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda") for _ in range(F)] if world > 1 else full
 
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def draw(i=0):
-        if tile:
-            res.draw_strips_device(W, H, shard.DEFAULT_STRIP_ROWS, rank, world, out.data_ptr(), stream=sptr)
-            if args.gather == "shm":      # D2H into pinned memory, then this rank's strips go to their place in the shared frame
-                with torch.cuda.stream(stream):
-                    pinned.copy_(out, non_blocking=True)
-                stream.synchronize()
-                shared.put_strips(pinned[:my_rows].numpy(), rank, world)
-                if world > 1:
-                    dist.barrier(group=gloo)
-            elif args.gather:             # final host-side gather (D2H + gloo), never RCCL
-                stream.synchronize()
-                shard.gather_image(out[:my_rows].cpu().numpy(), W, H, rank, world, group=gloo)
-        else:
-            ctxs[i].draw_device(W, H, outs[i].data_ptr(), stream=streams[i].cuda_stream)
+    def max_over_ranks(values):
+        if world == 1:
+            return [float(v) for v in values]
+        t = torch.tensor(list(values), dtype=torch.float64, device=red_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return [float(v) for v in t]
 
-    total = args.warmup + args.steps
-    unis = [uniforms_for(s) for s in range(total)]
-    # set-up, not a step: every context draws once so that its scratch buffers exist and the scene's kernel is compiled
-    # and loaded before anything is timed, however small --warmup is
-    for i in range(F):
-        ctxs[i].set_uniforms(unis[0])
-        draw(i)
-    torch.cuda.synchronize()
+    def prepare(c, u):
+        """RayMarchingCallback::prepare (renderer.rs:196-242): the uniform write and the rewrite of the command buffer the
+        reference does every frame (identical bytes: recognised by a memcmp, nothing is decoded or copied again)."""
+        c.set_uniforms(u)
+        c.set_program(cc, words)
 
-    def timed_run(n_ctx):
-        """W warm-up + K timed steps over the first n_ctx contexts.  Returns (seconds, mean per-draw ms from events,
-        mean march-kernel ms from the library's own events)."""
+    def draw_full(i):
+        ctxs[i].draw_device(W, H, full[i].data_ptr(), stream=streams[i].cuda_stream)
+
+    def draw_strips(i):
+        if my_rows:
+            ctxs[i].draw_strips_device(W, H, SR, rank, world, strips[i].data_ptr(), stream=streams[i].cuda_stream)
+
+    def timed(n_ctx, draw, unis, after_issue=None, finish=None):
+        """W warm-up + K timed steps over the first n_ctx contexts, bracketed by barrier + synchronize on both sides.
+        Returns (seconds [max over ranks], mean per-draw ms from HIP events on the launch stream, mean march-kernel ms
+        from the library's own events)."""
         for s in range(args.warmup):
-            ctxs[s % n_ctx].set_uniforms(unis[s])
+            prepare(ctxs[s % n_ctx], unis[s])
             draw(s % n_ctx)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         for c in ctxs[:n_ctx]:
             c.set_option(_ffi.RM_OPT_TIMING, 1)     # library-side HIP events around the march kernel itself
         sync_all()
         t0 = time.perf_counter()
-        for k in range(args.steps):
+        for k in range(K):
             i = k % n_ctx
-            ctxs[i].set_uniforms(unis[args.warmup + k])        # prepare(): uniform write
+            prepare(ctxs[i], unis[args.warmup + k])
             ev[k][0].record(streams[i])
-            draw(i)                                             # paint(): the kernels, on this frame's stream
+            draw(i)                                  # paint(): the kernels, on this frame's stream
             ev[k][1].record(streams[i])
+            if after_issue:
+                after_issue(k, i)
+        if finish:
+            finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         seconds = time.perf_counter() - t0
-        per_draw = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)    # all launches of a draw
-        kms = [c.info(_ffi.RM_INFO_KERNEL_MS) for c in ctxs[:n_ctx]]             # the dominant (march) kernel alone
+        per_draw = sum(a.elapsed_time(b) for a, b in ev) / max(1, K)
+        kms = [c.info(_ffi.RM_INFO_KERNEL_MS) for c in ctxs[:n_ctx]]
         for c in ctxs[:n_ctx]:
             c.set_option(_ffi.RM_OPT_TIMING, 0)
-        return seconds, per_draw, sum(kms) / len(kms)
+        seconds, per_draw, kms = max_over_ranks([seconds, per_draw, sum(kms) / len(kms)])
+        return seconds, per_draw, kms
 
-    elapsed, draw_ms, kernel_ms = timed_run(F)
+    cam_stride, cam_offset = (world, rank) if not tile else (1, 0)    # frames mode: rank r renders frames r, r + world, ...
+    unis = [uniforms(s, args.camera, cam_stride, cam_offset) for s in range(total)]
+    # set-up, not a step: every context draws once so that its scratch buffers exist and the scene's kernel is compiled
+    # and loaded before anything is timed, however small --warmup is
+    headline_draw = draw_strips if tile else draw_full
+    for i in range(F):
+        prepare(ctxs[i], unis[0])
+        headline_draw(i)
+    torch.cuda.synchronize()
+
+    # ---- headline: image(s) resident in HBM ------------------------------------------------------------------
+    elapsed, draw_ms, kernel_ms = timed(F, headline_draw, unis)
     specialized = bool(res.info(_ffi.RM_INFO_SPECIALIZED))                    # what the LAST timed launch ran
     jit_ms = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
-    if world > 1:
-        t = torch.tensor([elapsed, kernel_ms, draw_ms], dtype=torch.float64,
-                         device="cuda" if args.dist_backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, kernel_ms, draw_ms = float(t[0]), float(t[1]), float(t[2])
+    last = (strips if tile else full)[(K - 1) % F]
+    checksum = float(last[..., :3].double().sum().item())                     # touches the result: nothing was skipped
+    frames_per_step = 1 if tile else world
+    value = W * H * K * frames_per_step / elapsed / 1e6
 
-    checksum = float(outs[(args.steps - 1) % F][..., :3].double().sum().item())    # touches the result: nothing was skipped
+    legs = {}
+    if not args.no_legs:
+        # strictly serial loop (one frame in flight): what ONE frame costs, and the only honest source of per-launch
+        # durations (with several frames in flight an event-bracketed draw also contains time queued behind the others)
+        s_el, s_draw, s_k = timed(1, headline_draw, unis)
+        legs["one_frame_in_flight"] = {"value": W * H * K * frames_per_step / s_el / 1e6, "unit": "Mpixels/s",
+                                       "draw_ms": s_draw, "kernel_ms": s_k}
+        # end to end: the image lands in host memory.  N = 1: D2H into one pinned frame; N > 1: the north-star gather --
+        # every rank copies its strips to their rows of ONE shared-memory frame (two frame slots, frame k -> slot k % 2,
+        # so frame k + 1 renders while frame k is copied), a per-rank completion counter says when a frame is whole.
+        if args.camera == "still" or tile:
+            D = 2 if F >= 2 else 1
+            name = "rm_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
+            gloo = dist.new_group(backend="gloo") if (world > 1 and args.dist_backend != "gloo") else None
 
-    # Legs after the timed region (N = 1 only), reported beside the headline number:
-    #   one_frame_in_flight     the strictly serial loop (what an interactive frame costs end to end)
-    #   ab_interpreter_kernel   the same, through the interpreter kernel, i.e. the design north_star spells out
-    #                           (node array staged in LDS and INTERPRETED)
-    serial = ab = None
-    if world == 1 and not tile and not args.no_ab:
-        if F > 1:
-            s_el, s_draw, s_k = timed_run(1)
-            serial = {"value": W * H * args.steps / s_el / 1e6, "unit": "Mpixels/s", "draw_ms": s_draw, "kernel_ms": s_k,
-                      "same_image": float(outs[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
-        if specialized:
+            def host_barrier():
+                if world > 1:
+                    dist.barrier(group=gloo) if gloo is not None else dist.barrier()
+
+            shared = shard.SharedImage(name, W, H, slots=D).open(rank, world, host_barrier)
+            shared.register()
+            done = [torch.cuda.Event() for _ in range(D)]
+            state = {"base": 0}
+
+            def deliver(k):      # frame k of this leg has left this rank's GPU; wait until it is whole on the host
+                done[k % D].synchronize()
+                shared.mark_done(rank, state["base"] + k + 1)
+                shared.wait_all(state["base"] + k + 1)
+
+            def after_issue(k, i):
+                if my_rows:
+                    ctxs[i].gather_strips(W, H, SR, rank, world, strips[i].data_ptr(), shared.slot_address(k),
+                                          stream=streams[i].cuda_stream)
+                done[k % D].record(streams[i])
+                if k >= D - 1:
+                    deliver(k - (D - 1))
+
+            def finish():
+                for k in range(max(0, K - (D - 1)), K):
+                    deliver(k)
+
+            e_el, _, _ = timed(D, draw_strips if world > 1 else draw_full, unis, after_issue, finish)
+            state["base"] += K
+            host_barrier()
+            e2e = {"value": W * H * K / e_el / 1e6, "unit": "Mpixels/s", "ms_per_frame": e_el / K * 1e3,
+                   "what": ("frame tiled over %d GPUs + host-side gather: each rank's strips D2H straight into their rows of one "
+                            "page-locked POSIX shared-memory frame (rm_gather_strips), completion counter per rank, two frames "
+                            "in flight" % world) if world > 1
+                   else "draw + D2H of the frame into page-locked host memory (rm_gather_strips), two frames in flight"}
+            if rank == 0:
+                # the gathered frame must be the frame one GPU renders, byte for byte (tiling invariance)
+                prepare(ctxs[0], unis[-1])
+                draw_full(0)
+                torch.cuda.synchronize()
+                e2e["gathered_frame_identical_to_one_gpu_render"] = bool(
+                    (torch.from_numpy(shared.slot((K - 1) % D)) == full[0].cpu()).all().item()) if args.camera == "still" else None
+            legs["end_to_end"] = e2e
+            shared.close(host_barrier)
+        if world > 1 and tile:
+            # the other partition of north_star (BASELINE config 5): whole frames per rank, no gather
+            funis = [uniforms(s, args.camera, world, rank) for s in range(total)]
+            for i in range(F):
+                prepare(ctxs[i], funis[0])
+                draw_full(i)
+            torch.cuda.synchronize()
+            f_el, _, _ = timed(F, draw_full, funis)
+            legs["frames_sharded"] = {"value": W * H * K * world / f_el / 1e6, "unit": "Mpixels/s", "scaling": "weak",
+                                      "what": "every rank renders whole frames (frame f -> rank f %% %d), %d in flight per rank" % (world, F)}
+        if world == 1 and args.camera == "still":
+            # an orbiting camera: every frame a new view, so the temporal tile order (RM_OPT_BALANCE = 3) predicts from a
+            # neighbouring frame instead of the identical one
+            ounis = [uniforms(s, "orbit") for s in range(total)]
+            o_el, _, _ = timed(F, draw_full, ounis)
+            legs["orbit_camera"] = {"value": W * H * K / o_el / 1e6, "unit": "Mpixels/s",
+                                    "what": "same loop, frame f of a 1024-frame orbit (yaw 2 pi f / 1024, pitch -0.25, r 5)"}
+        if world == 1 and specialized:
+            # A/B: the interpreter kernel, i.e. the design north_star spells out (node array staged in LDS and INTERPRETED)
             res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
-            a_el, a_draw, a_k = timed_run(1)
-            ab = {"kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine), one frame in flight",
-                  "value": W * H * args.steps / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
-                  "same_image": float(outs[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
+            a_el, _, a_k = timed(1, draw_full, unis)
+            legs["ab_interpreter_kernel"] = {
+                "kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine), one frame in flight",
+                "value": W * H * K / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
+                "same_image": float(full[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
             res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
+
     if rank == 0:
-        pixels = W * H * args.steps * (1 if tile else world)
-        value = pixels / elapsed / 1e6
-        # whole-frame algorithmic bytes over the whole draw (pre-pass + sort + march kernel launches)
-        # launch duration of one frame's three kernels: with several frames in flight the event-bracketed draw also
-        # contains the time spent queued behind the other frame, so the serial leg's figure is the one that applies
-        draw_ms_launch = serial["draw_ms"] if serial is not None else draw_ms
-        ach = BYTES_PER_PIXEL * W * (my_rows if tile else H) / (draw_ms_launch * 1e-3) / 1e9
+        serial = legs.get("one_frame_in_flight")
+        # per-launch figures come from the serial leg; without it (--no-legs) from the headline loop, labelled as such
+        launch_draw_ms = serial["draw_ms"] if serial else draw_ms
+        launch_kernel_ms = serial["kernel_ms"] if serial else kernel_ms
+        rows_here = my_rows if tile else H
+        ach = BYTES_PER_PIXEL * W * rows_here / (launch_draw_ms * 1e-3) / 1e9
         traffic = None
-        tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tfile):
+        if world == 1:
             try:
-                with open(tfile) as f:
+                with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
                     traffic = json.load(f).get("%s_%dx%d_%d" % (args.scene, W, H, args.max_iter))
-            except Exception:
+            except (OSError, ValueError):
                 traffic = None
+        if tile:
+            sharding = ("every frame tiled over %d ranks in interleaved %d-row strips (rm_draw_strips: all of a rank's strips in one "
+                        "launch), strips resident in each GPU's HBM; no collective; `end_to_end` adds the host-side gather into one "
+                        "shared-memory frame" % (world, SR))
+        else:
+            sharding = ("frames over ranks (frame f -> rank f %% %d), no collective" % world) if world > 1 else "single GPU"
         line = {
             "metric": "Mpixels/s at 1920x1080, 256-step march, 32-node SDF",
-            "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if tile else "weak",
+            "value": value, "unit": "Mpixels/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True,
+            "scaling": None if world == 1 else ("strong" if tile else "weak"),
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%dx%d, %s (%d commands / %d words), %d max steps, 16 rays/px, RGBA32F out"
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
-                       "camera": args.camera, "kernel": args.kernel,
-                       "specialized_kernel": specialized, "jit_compile_ms": jit_ms, "frames_in_flight": F,
-                       "sharding": ("one frame tiled over ranks in interleaved 16-row strips%s, no collective"
-                                    % ((" + host gather (%s)" % args.gather) if args.gather else "")) if tile
-                       else ("frames over ranks, no collective" if world > 1 else "single GPU")},
+                       "step": "prepare (uniform write + command-buffer rewrite, renderer.rs:213-239) + draw, image resident in HBM",
+                       "camera": args.camera, "kernel": args.kernel, "specialized_kernel": specialized,
+                       "jit_compile_ms": jit_ms, "frames_in_flight": F, "sharding": sharding},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("rm_render_v5_spec (hipRTC-compiled for this scene's structure)" if specialized else "rm_render_v5")
-                                   + " = the dominant (march) kernel: kernel_ms; `achieved` divides the frame's "
-                                   "bytes by draw_ms, the draw's three launches (pre-pass, sort, march)",
-                         "kernel_ms": kernel_ms, "draw_ms": draw_ms,
-                         "draw_ms_one_frame_in_flight": draw_ms_launch,
-                         "frames_in_flight_note": ("%d frames in flight: a frame's event-bracketed draw_ms includes queueing behind "
-                                                   "the other frame and exceeds ms_per_step; `achieved` uses the launch duration "
-                                                   "of the same three kernels measured without overlap in this run "
-                                                   "(one_frame_in_flight), when that leg ran" % F) if F > 1 else None,
-                         "note": "algorithmic bytes = 16 B/pixel (one RGBA32F store); the kernel is FP32-VALU "
-                                 "bound by ~3 orders of magnitude, see `compute`"},
+                                   + ", the dominant (march) kernel",
+                         "kernel_ms": launch_kernel_ms, "draw_ms": launch_draw_ms,
+                         "timing": ("one frame in flight: HIP events on the launch stream; kernel_ms = the march kernel alone, draw_ms = "
+                                    "the draw's three launches (pre-pass, sort, march), which `achieved` divides this GPU's %d x %d x 16 "
+                                    "bytes by" % (W, rows_here)) if serial else "headline loop (frames overlap: upper bounds)",
+                         "note": "algorithmic bytes = 16 B/pixel (one RGBA32F store); the kernel is FP32-VALU bound by ~3 orders of "
+                                 "magnitude, see `compute`"},
             "checksum_rgb": checksum,
         }
-        if world == 1:
+        if world == 1 and not args.no_legs:
             # the measured HBM-write ceiling of this GPU, same run: a fill kernel with 16 B/lane stores over 1 GiB
             # (SURVEY 8(d)); the declared peak above stays the spec figure
             try:
@@ -319,10 +418,7 @@ def main():
             except Exception as e:      # diagnostics only
                 line["roofline"]["measured_write_GBps"] = None
                 line["roofline"]["measured_write_error"] = str(e)
-        if serial is not None:
-            line["one_frame_in_flight"] = serial
-        if ab is not None:
-            line["ab_interpreter_kernel"] = ab
+        line.update(legs)
         if world == 1 and not args.no_cpu_baseline:
             base, cnt, (cw, ch) = cpu_baseline(args, (cc, words), still_events)
             line["cpu_baseline"] = base
@@ -331,21 +427,21 @@ def main():
                 scale = (W * H) / float(cw * ch)
                 evals = (cnt["march_steps"] + cnt["normal_taps"]) * scale
                 line["compute"] = {"map_scene_evals_per_frame": evals,
-                                   "evals_per_s": evals / (kernel_ms * 1e-3),
+                                   "evals_per_s": evals / (launch_kernel_ms * 1e-3),
                                    "note": "evaluations counted by the oracle on the CPU sample, scaled by pixel count"}
-                line["compute"].update(valu_view(args, res, serial["kernel_ms"] if serial else kernel_ms, evals, words))
+                line["compute"].update(valu_view(args, res, launch_kernel_ms, evals, words))
         print(json.dumps(line), flush=True)
     for c in ctxs:
         c.close()
-    if shared is not None:
-        shared.close((lambda: dist.barrier(group=gloo)) if world > 1 else None)
     if world > 1:
         dist.destroy_process_group()
 
 
 def valu_view(args, res, march_ms, evals, words):
-    """The honest bound: FP32 vector issue.  Instruction counts come from the committed PMC pass of this
-    configuration (profiles/pmc_traffic.json), the duration from this run (march kernel, no other frame in flight)."""
+    """The honest bound: FP32 vector issue.  Instruction counts and the clock come from the committed PMC
+    pass of this configuration (profiles/pmc_traffic.json), the duration from this run (march kernel, one frame in
+    flight).  Floor: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md), transcendental
+    ones for 4 (profiles/r02_ubench_valu_issue_cycles.txt)."""
     from ray_marching_amd import _ffi
     out = {}
     # algorithmic flops of the reference's map_scene for this program (SURVEY 8(d): 10 / sphere, 22 / box, 1 / union,
@@ -366,22 +462,35 @@ def valu_view(args, res, march_ms, evals, words):
     if pmc:
         simds = 4.0 * res.info(_ffi.RM_INFO_CU_COUNT)
         insts = pmc["SQ_INSTS_VALU"]
-        flop_insts = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + pmc["SQ_INSTS_VALU_TRANS_F32"]
-        ns_per_inst = march_ms * 1e6 * simds / insts
+        trans = pmc.get("SQ_INSTS_VALU_TRANS_F32", 0.0)
+        clock_ghz = pmc.get("clock_ghz", 2.4)
+        flop_insts = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + trans
+        cycles_per_inst = march_ms * 1e-3 * clock_ghz * 1e9 * simds / insts
+        floor_cycles = (VALU_CYCLES_PER_WAVE_INST * (insts - trans) + pmc.get("trans_issue_cycles", 4.0) * trans) / insts
         out.update({
             "bound": "fp32 valu issue",
             "valu_insts_per_frame": insts,
-            "ns_per_valu_inst_per_simd": ns_per_inst,
-            "fastest_valu_issue_ns_per_simd": pmc["fastest_valu_issue_ns_per_simd"],
-            "frac_of_valu_issue": pmc["fastest_valu_issue_ns_per_simd"] / ns_per_inst,
+            "clock_ghz": clock_ghz,
+            "cycles_per_valu_inst_per_simd": cycles_per_inst,
+            "issue_floor_cycles_per_inst": floor_cycles,
+            "frac_of_valu_issue": floor_cycles / cycles_per_inst,
             "executed_fp32_TFLOPs": flop_insts * 64.0 * pmc["lane_occupancy"] / (march_ms * 1e-3) / 1e12,
-            "peak_fp32_vector_TFLOPs": 157.3,
-            "valu_note": "instruction counts: committed rocprofv3 PMC pass of this configuration; issue floor: fastest class of "
-                         "profiles/r01_ubench_valu_issue_rates.txt (v_add / v_mul / v_fma; min / max / cmp / transcendental ops issue "
-                         "slower); the 157.3 TFLOP/s peak assumes packed FMAs, the contract forbids fusing (DESIGN 2)",
+            "peak_fp32_vector_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
+            "valu_note": "instruction counts and clock: committed rocprofv3 PMC pass of this configuration (" + pmc.get("source", "profiles/") +
+                         "); floor: 2 cycles per wave64 VALU instruction on a SIMD-32, transcendentals more; the 157.3 TFLOP/s peak "
+                         "assumes packed FMAs, the arithmetic contract forbids fusing (DESIGN 2)",
         })
     return out
 
 
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    run_rank(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

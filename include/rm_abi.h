@@ -22,9 +22,11 @@
  * `int` returns RM_OK (0) or a negative rm_status; nothing throws or unwinds across the
  * ABI.  The caller owns every pointer it passes in; the library copies before returning.
  * An rm_ctx is bound to one GPU and is externally synchronised (one thread at a time);
- * different contexts may be used concurrently from different threads/processes.  Asynchronous
- * (device-destination) draws of ONE context share its scratch buffers: issue them on one stream,
- * or wait for a draw before issuing the next on another stream.  Buffer writes are ordered with the
+ * different contexts may be used concurrently from different threads/processes.  All draws of ONE
+ * context share its scratch buffers and therefore execute in the order they were issued: a draw issued
+ * on another stream than the context's previous draw (a host-destination draw runs on the context's own
+ * stream) first waits for everything queued on that previous stream.  Frames that should overlap use
+ * one context each (RM_STREAM_OWN below).  Buffer writes are ordered with the
  * draws like queue.write_buffer is in wgpu (renderer.rs:213-239): limits and uniforms travel with each
  * draw as kernel arguments; a changed program (and the cameras of rm_draw_batch) is copied to the GPU on
  * the stream of the next draw, behind the draws already queued there, so a frame that is still in flight
@@ -47,7 +49,7 @@
 extern "C" {
 #endif
 
-#define RM_ABI_VERSION 1
+#define RM_ABI_VERSION 2 /* 2: kernel variants 2..11 (v2-v4) retired; rm_gather_strips, rm_host_register added */
 
 typedef struct rm_ctx rm_ctx;
 
@@ -108,15 +110,15 @@ enum rm_option {
     RM_OPT_TIMING = 1,     /* 1: bracket every launch of the dominant (march) kernel with HIP events on its stream,
                               without synchronising; read with rm_get_info(RM_INFO_KERNEL_MS) */
     RM_OPT_STRICT_CAP = 2, /* reserved */
-    RM_OPT_REFILL_MIN = 3, /* raypool kernels: parked lanes that trigger a refill, 1..64 (default 8) */
-    RM_OPT_CULL = 4,       /* v3 kernels: 1 (default) = shade rays that provably miss the scene without marching */
+    RM_OPT_REFILL_MIN = 3, /* idle lanes of a wave that trigger a refill from the tile's ray pool, 1..64 (default 1) */
+    RM_OPT_CULL = 4,       /* 1 (default) = shade rays that provably miss the scene without marching (exact) */
     RM_OPT_BALANCE = 5,    /* dispatch order of the tiles that need marching (it never changes a pixel): 0 raster order;
                               1 most pending pixels first; 2 partially covered tiles first; 3 (default) the tiles that
                               took longest in the context's previous draw of the same shape first -- consecutive frames
                               of a view look alike, and a kernel that ends on its shortest tiles has no tail
                               (one frame at a time: +6-9 %); the first draw of a shape falls back to 1 */
-    RM_OPT_WAVES_PER_TILE = 7, /* v3 kernels: waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
-    RM_OPT_WAVE_STATS = 6, /* diagnostics: v3 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
+    RM_OPT_WAVES_PER_TILE = 7, /* waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
+    RM_OPT_WAVE_STATS = 6, /* diagnostics: the v5 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
     RM_OPT_OUTPUT_FORMAT = 10, /* enum rm_format: what rm_draw / rm_draw_strips / rm_draw_batch write (default RM_FORMAT_RGBA32F).
                                   The 8-bit formats are the output stage of SURVEY 8(f)-3: the reference's own colour target is
                                   the 8-bit egui surface (renderer.rs:113).  Only the default (v5) kernels implement them. */
@@ -140,18 +142,15 @@ enum rm_format {
     RM_FORMAT_BGRA8_UNORM = 2   /* 4 B/pixel: bytes b, g, r, a (wgpu's usual surface format) */
 };
 enum rm_kernel {
-    RM_KERNEL_DEFAULT = 0,   /* the tuned kernel */
-    RM_KERNEL_PIXEL = 1,     /* v1: one thread per pixel, program staged in LDS, lock-step AA loop */
-    RM_KERNEL_RAYPOOL = 2,   /* v2: per-wave ray pool, ballot-driven refill, program through the scalar cache */
-    RM_KERNEL_RAYPOOL_LDS = 3, /* v2 with the program read from LDS */
-    /* v3: ray pool with R rays in flight per lane, lean interpreter (scalar-cache / LDS program) */
-    RM_KERNEL_MULTI1 = 4, RM_KERNEL_MULTI1_LDS = 5,
-    RM_KERNEL_MULTI2 = 6, RM_KERNEL_MULTI2_LDS = 7,
-    RM_KERNEL_MULTI4 = 8, RM_KERNEL_MULTI4_LDS = 9,
-    /* v4: ray pool with LDS ready/shade queues: ray generation, culling and shading run 64 rays at a time */
-    RM_KERNEL_QUEUE = 10, RM_KERNEL_QUEUE_LDS = 11,
-    /* v5: v3 with full-width ray production / shading through per-wave LDS rings and a sharper miss test */
-    RM_KERNEL_V5 = 12, RM_KERNEL_V5_LDS = 13
+    RM_KERNEL_DEFAULT = 0,   /* the tuned kernel: v5 with the program staged in LDS, its march kernel compiled per program
+                                structure (RM_OPT_SPECIALIZE) */
+    RM_KERNEL_PIXEL = 1,     /* v1: north_star's literal design -- one thread per pixel, program staged in LDS, lock-step AA
+                                and march loops (reference node types only); kept as the A/B reference point */
+    /* 2..11 were the v2-v4 ray-pool / queue experiments of ABI version 1; retired (DESIGN.md 5 keeps their measurements) */
+    /* v5: ray pool shared by the waves of a tile, full-width ray production / shading through per-wave LDS buffers, exact
+       miss tests, persistent workgroups over a sorted work list; the interpreter form (RM_OPT_SPECIALIZE = 0) of the default */
+    RM_KERNEL_V5 = 12,       /* program read through the scalar cache (what programs too long for LDS fall back to) */
+    RM_KERNEL_V5_LDS = 13    /* program staged in LDS once per workgroup */
 };
 enum rm_info {
     RM_INFO_KERNEL_MS = 0,       /* mean duration (ms) of the march kernel over the launches timed since the last query
@@ -223,6 +222,18 @@ int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, f
  * strip).  Interleaving balances the load: the costly part of a frame is usually its centre. */
 int rm_draw_strips(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,
                    float* out_rgba, int out_is_device, void* stream, uint32_t* out_rows);
+
+/* The final host-side gather of a tiled frame (north-star: "a final host-side gather (no RCCL collectives)"):
+ * copies the strips rm_draw_strips(first, stride) wrote back to back into `strips_device` to their rows of the full
+ * W x H host image `host_image` (pixel size per RM_OPT_OUTPUT_FORMAT), asynchronously on `stream` (as rm_draw's stream).
+ * Every GPU of the node targets the same image -- e.g. one POSIX shared-memory segment mapped by all rank processes and
+ * registered with rm_host_register -- and writes only its own rows: no rank relays another rank's pixels and the only
+ * inter-process traffic is a "frame complete" flag.  With unregistered (pageable) memory the copies are synchronous. */
+int rm_gather_strips(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,
+                     const void* strips_device, void* host_image, void* stream);
+/* Page-locks / unlocks caller-owned host memory (hipHostRegister) so that copies into it run asynchronously at PCIe rate. */
+int rm_host_register(void* ptr, uint64_t bytes);
+int rm_host_unregister(void* ptr);
 
 /* n_frames draws that differ only in their uniforms (camera-orbit batch); frame f is
  * written at out_rgba + f*W*H*4. */

@@ -32,10 +32,7 @@ RM_ERR_NO_DEVICE, RM_ERR_ARG, RM_ERR_TRANSFORM, RM_ERR_MATERIAL = -10, -11, -12,
 RM_BUF_LIMITS, RM_BUF_COMMANDS, RM_BUF_UNIFORMS = 0, 1, 2
 RM_OPT_KERNEL, RM_OPT_TIMING, RM_OPT_STRICT_CAP, RM_OPT_REFILL_MIN, RM_OPT_CULL = 0, 1, 2, 3, 4
 RM_OPT_BALANCE, RM_OPT_WAVE_STATS, RM_OPT_WAVES_PER_TILE, RM_OPT_SPECIALIZE, RM_OPT_PRUNE = 5, 6, 7, 8, 9
-RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL, RM_KERNEL_RAYPOOL, RM_KERNEL_RAYPOOL_LDS = 0, 1, 2, 3
-RM_KERNEL_MULTI1, RM_KERNEL_MULTI1_LDS, RM_KERNEL_MULTI2, RM_KERNEL_MULTI2_LDS = 4, 5, 6, 7
-RM_KERNEL_MULTI4, RM_KERNEL_MULTI4_LDS = 8, 9
-RM_KERNEL_QUEUE, RM_KERNEL_QUEUE_LDS = 10, 11
+RM_KERNEL_DEFAULT, RM_KERNEL_PIXEL = 0, 1      # 2..11: the retired v2-v4 variants of ABI version 1
 RM_KERNEL_V5, RM_KERNEL_V5_LDS = 12, 13
 RM_JIT_PRUNE = 0x100
 RM_STREAM_OWN = (1 << 64) - 1   # (void*)-1: the context's own stream
@@ -102,6 +99,12 @@ def hip_lib():
         L.rm_draw_strips.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int, vp, C.POINTER(u32)]
         L.rm_draw_strips.restype = C.c_int
         L.rm_draw_batch.argtypes = [vp, C.POINTER(Uniforms), u32, u32, u32, vp, C.c_int, vp]
+        L.rm_gather_strips.argtypes = [vp, u32, u32, u32, u32, u32, vp, vp, vp]
+        L.rm_gather_strips.restype = C.c_int
+        L.rm_host_register.argtypes = [vp, u64]
+        L.rm_host_register.restype = C.c_int
+        L.rm_host_unregister.argtypes = [vp]
+        L.rm_host_unregister.restype = C.c_int
         L.rm_sync.argtypes = [vp]
         L.rm_sync_context.argtypes = [vp]
         L.rm_sync_context.restype = C.c_int

@@ -16,8 +16,7 @@
 #include "rm_jit.h"
 #include "rm_device.h"
 #include "rm_kernels.h"
-#include "rm_kernel_multi.h"
-#include "rm_kernel_queue.h"
+#include "rm_interp.h"
 #include "rm_kernel_v5.h"
 
 #define RM_EXPORT extern "C" __attribute__((visibility("default")))
@@ -39,6 +38,13 @@ struct rm_ctx {
     int cu_count = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // Draws of one context share its scratch (program copy, tile cost / order / counters / measurements).  They are
+    // ordered by their stream; when a draw arrives on ANOTHER stream than the previous one (a host-destination draw
+    // runs on the context's own stream, device-destination draws on the caller's), the new stream first waits for
+    // everything queued on the previous one: order_with_previous().
+    hipStream_t last_stream = nullptr;
+    bool last_stream_valid = false;
+    hipEvent_t ev_order = nullptr;
     // RM_OPT_TIMING: one event pair per timed launch of the dominant kernel, read back (and
     // reset) by rm_get_info(RM_INFO_KERNEL_MS): no synchronisation inside the launch path.
     std::vector<std::pair<hipEvent_t, hipEvent_t>> tev;
@@ -68,7 +74,6 @@ struct rm_ctx {
     size_t d_frames_cap = 0;
     // options / info
     int kernel = RM_KERNEL_DEFAULT;
-    uint32_t refill_min = 8;
     uint32_t refill_min_v5 = 1;
     bool cull = true;
     int balance = 3;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first,
@@ -265,12 +270,39 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     std::lock_guard<std::mutex> lk(e->m);
     rmjit::Entry::Loaded& l = e->loaded[c->device];
     if (!l.function && !l.module && !e->code.empty()) {
-        hipModule_t mod = nullptr;
-        hipFunction_t fn = nullptr;
-        if (hipModuleLoadData(&mod, e->code.data()) == hipSuccess &&
-            hipModuleGetFunction(&fn, mod, rmjit::kernel_name()) == hipSuccess) {
-            l.module = mod;
-            l.function = fn;
+        auto load = [&]() -> bool {
+            hipModule_t mod = nullptr;
+            hipFunction_t fn = nullptr;
+            if (hipModuleLoadData(&mod, e->code.data()) == hipSuccess &&
+                hipModuleGetFunction(&fn, mod, rmjit::kernel_name()) == hipSuccess) {
+                l.module = mod;
+                l.function = fn;
+                return true;
+            }
+            (void)hipGetLastError();
+            if (mod) (void)hipModuleUnload(mod);
+            return false;
+        };
+        bool ok = load();
+        if (!ok && !e->cached_source.empty()) {
+            // the code object came from the disk cache and the loader rejects it (written by another driver stack, or
+            // damaged in a way the checksum cannot see): drop the file and compile the source afresh, once
+            const std::string src = std::move(e->cached_source);
+            e->cached_source.clear();
+            const std::string file = rmjit::cache_path(src);
+            if (!file.empty()) std::remove(file.c_str());
+            std::string log;
+            double ms = 0.0;
+            e->code.clear();
+            if (rmjit::compile(src, &e->code, &log, &ms)) {
+                e->compile_ms = ms;
+                e->log += "\ncached code object rejected by the loader; recompiled";
+                ok = load();
+            } else {
+                e->log += "\n" + log;
+            }
+        }
+        if (ok) {
             // an evicted entry (more than 256 structures in one process) may still have launches in flight on a
             // context that moved on to another program: wait for the device before the code object goes away
             e->unload = [](void* m, int device) {
@@ -282,8 +314,6 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
                 (void)hipGetLastError();
             };
         } else {
-            (void)hipGetLastError();
-            if (mod) (void)hipModuleUnload(mod);
             e->log += "\nloading the compiled module failed";
             e->code.clear();  // do not try again
         }
@@ -309,57 +339,6 @@ int ensure_stats(rm_ctx* c, RmLaunch& L, size_t n_waves);
 int finish_launch(rm_ctx* c, hipStream_t s);
 int time_begin(rm_ctx* c, hipStream_t s);
 int time_end(rm_ctx* c, hipStream_t s);
-
-template <int R, int WPT>
-int launch_multi_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
-    using G = rmk::TileGeom<R>;
-    RmLaunch L = L_in;
-    if (c->decoded.has_extensions)
-        return fail(c, RM_ERR_ARG, "the v3 kernels render reference node types only (program uses extension nodes)");
-    // Miss-ray culling: one table entry per command, kept in LDS; very long programs go without.
-    // An empty scene evaluates to max_dist everywhere (wgsl:189-191): no ray can hit unless
-    // max_dist < min_dist, so (only) then the all-miss shortcut must stay off.
-    bool cull = c->cull && L.n_rec <= 256u && !c->decoded.has_extensions;  // v3's cone table knows spheres and boxes only
-    if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;
-    L.n_cull = cull ? L.n_rec : 0u;
-    L.flags = cull ? 1u : 0u;
-    const uint32_t n_tiles = ((L.W + G::TW - 1u) / G::TW) * ((L.rows + G::TH - 1u) / G::TH);
-    dim3 grid(n_tiles, 1, n_frames);
-    size_t shmem = (size_t)18u * G::PIX * sizeof(float) + (size_t)L.spill_depth * R * 64u * WPT * sizeof(float) +
-                   (size_t)L.n_cull * 16u + (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u) + 16u;
-    if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
-    // Heaviest-tile-first dispatch order (see rm_tile_cost); pointless when nothing can be culled
-    // cheaply estimated (culling off) or when the frame has fewer tiles than the chip has wave slots.
-    if (c->balance && cull && L.n_rec != 0u && L.max_iter != 0u) {
-        if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
-        hipLaunchKernelGGL((rmk::rm_tile_cost<R>), grid, dim3(64), (size_t)L.n_cull * 16u, s, L, c->d_cost);
-        hipLaunchKernelGGL(rmk::rm_tile_sort, dim3(n_frames), dim3(1024), 0, s, c->d_cost, c->d_order, n_tiles);
-        L.order = c->d_order;
-    }
-    if (int rc = ensure_stats(c, L, (size_t)n_tiles * n_frames * WPT)) return rc;
-    if (int rc = time_begin(c, s)) return rc;
-    if (lds)
-        hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgLds, true, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
-    else
-        hipLaunchKernelGGL((rmk::rm_render_raypool_multi<rmk::ProgSmem, false, R, WPT>), grid, dim3(64 * WPT), shmem, s, L, c->refill_min);
-    if (int rc = time_end(c, s)) return rc;
-    return finish_launch(c, s);
-}
-
-template <int R>
-int launch_multi(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
-    // Deep value stacks spill [depth][R][64] floats per wave: use fewer waves per tile when the
-    // requested number would not fit the LDS budget of one workgroup.
-    int wpt = c->waves_per_tile;
-    const size_t fixed = (size_t)18u * rmk::TileGeom<R>::PIX * 4u + (size_t)L.n_rec * (16u + (lds ? sizeof(RmRecord) : 0u)) + 16u;
-    while (wpt > 1 && fixed + (size_t)L.spill_depth * R * 64u * 4u * wpt > 48u * 1024u) wpt /= 2;
-    switch (wpt) {
-    case 1: return launch_multi_w<R, 1>(c, L, lds, n_frames, s);
-    case 2: return launch_multi_w<R, 2>(c, L, lds, n_frames, s);
-    case 8: return launch_multi_w<R, 8>(c, L, lds, n_frames, s);
-    default: return launch_multi_w<R, 4>(c, L, lds, n_frames, s);
-    }
-}
 
 template <int WPT>
 int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
@@ -435,38 +414,22 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
     int wpt = c->waves_per_tile;
-    const size_t fixed = 4096u + (size_t)L.n_rec * (48u + (lds ? sizeof(RmRecord) : 0u)) + (lds ? (size_t)L.n_grp * sizeof(RmRecord) : 0u) +
-                         16u + (L.n_mrec != 0u ? 1024u : 0u);
+    const size_t cull_bytes = L.n_rec <= 256u ? (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u : 0u;  // tables exist up to 256 records
+    const size_t prog_bytes = (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord);
     const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
-    while (wpt > 1 && fixed + (size_t)wpt * (rmk::V5_WAVE_DWORDS * 4u + depth * 256u) > 48u * 1024u)
-        wpt /= 2;
+    const size_t per_wave = rmk::V5_WAVE_DWORDS * 4u + depth * 256u;
+    const size_t fixed = 4096u + cull_bytes + 16u + sizeof(rm_uniforms) + (L.n_mrec != 0u ? 1024u : 0u);
+    // A long program (rm_resize_command_buffer admits 64 KB of commands, ~2 700 leaves = 85 KB of records) does not fit
+    // a workgroup's LDS next to the ray buffers: it is then read through the scalar cache instead (ProgSmem).
+    if (lds && fixed + prog_bytes + per_wave > 60u * 1024u) lds = false;
+    const size_t fixed_all = fixed + (lds ? prog_bytes : 0u);
+    while (wpt > 1 && fixed_all + (size_t)wpt * per_wave > 48u * 1024u) wpt /= 2;
     switch (wpt) {
     case 1: return launch_v5_w<1>(c, L, lds, n_frames, s);
     case 2: return launch_v5_w<2>(c, L, lds, n_frames, s);
     case 8: return launch_v5_w<8>(c, L, lds, n_frames, s);
     default: return launch_v5_w<4>(c, L, lds, n_frames, s);
     }
-}
-
-int launch_queue(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
-    RmLaunch L = L_in;
-    if (c->decoded.has_extensions)
-        return fail(c, RM_ERR_ARG, "the v4 kernels render reference node types only (program uses extension nodes)");
-    bool cull = c->cull && L.n_rec <= 256u;
-    if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi
-    L.n_cull = cull ? L.n_rec : 0u;
-    L.flags = cull ? 1u : 0u;
-    dim3 grid((L.W + 7u) / 8u, (L.rows + 7u) / 8u, n_frames);
-    size_t shmem = (size_t)(1024u + 4u * rmk::QCAP + 7u * rmk::QCAP) * 4u + (size_t)L.spill_depth * 64u * 4u +
-                   (size_t)L.n_cull * 16u + (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u);
-    if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per wave", shmem);
-    if (int rc = time_begin(c, s)) return rc;
-    if (lds)
-        hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgLds, true>), grid, dim3(64), shmem, s, L);
-    else
-        hipLaunchKernelGGL((rmk::rm_render_queue<rmk::ProgSmem, false>), grid, dim3(64), shmem, s, L);
-    if (int rc = time_end(c, s)) return rc;
-    return finish_launch(c, s);
 }
 
 struct StripSpec { uint32_t rows = 0, first = 0, stride = 0; };
@@ -504,36 +467,17 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.stats = nullptr;
     L.u = c->uniforms;
     int kernel = c->kernel == RM_KERNEL_DEFAULT ? RM_KERNEL_V5_LDS : c->kernel;
-    if (kernel == RM_KERNEL_RAYPOOL || kernel == RM_KERNEL_RAYPOOL_LDS || kernel == RM_KERNEL_PIXEL) {
-        if (c->decoded.has_extensions)
-            return fail(c, RM_ERR_ARG, "kernel variant %d renders reference node types only (program uses extension nodes)", kernel);
-        if (int rc = time_begin(c, s)) return rc;
-    }
-    switch (kernel) {
-    case RM_KERNEL_RAYPOOL:
-    case RM_KERNEL_RAYPOOL_LDS: {
-        dim3 grid((W + 7u) / 8u, (rows + 7u) / 8u, n_frames);
-        const bool lds = kernel == RM_KERNEL_RAYPOOL_LDS;
-        size_t shmem = (1024u + 128u) * sizeof(float) + (size_t)L.spill_depth * 64u * sizeof(float) +
-                       (lds ? (size_t)L.n_rec * sizeof(RmRecord) : 0u);
-        if (shmem > 160u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS", shmem);
-        if (lds)
-            hipLaunchKernelGGL((rmk::rm_render_raypool<rmk::ProgLds, true>), grid, dim3(64), shmem, s, L, c->refill_min);
-        else
-            hipLaunchKernelGGL((rmk::rm_render_raypool<rmk::ProgSmem, false>), grid, dim3(64), shmem, s, L, c->refill_min);
-    } break;
-    case RM_KERNEL_PIXEL: {
+    if (kernel == RM_KERNEL_V5 || kernel == RM_KERNEL_V5_LDS) return launch_v5(c, L, kernel == RM_KERNEL_V5_LDS, n_frames, s);
+    if (kernel != RM_KERNEL_PIXEL) return fail(c, RM_ERR_ARG, "kernel variant %d is not available", kernel);
+    // v1: north_star's literal design (one thread per pixel, program staged in LDS, lock-step loops); reference node types only
+    if (c->decoded.has_extensions)
+        return fail(c, RM_ERR_ARG, "kernel variant %d renders reference node types only (program uses extension nodes)", kernel);
+    if (int rc = time_begin(c, s)) return rc;
+    {
         dim3 grid((W + 15u) / 16u, (rows + 15u) / 16u, n_frames);
         size_t shmem = (size_t)L.n_rec * sizeof(RmRecord) + (size_t)L.spill_depth * 256u * sizeof(float);
+        if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per workgroup", shmem);
         hipLaunchKernelGGL(rmk::rm_render_pixel, grid, dim3(256), shmem, s, L);
-    } break;
-    case RM_KERNEL_V5: case RM_KERNEL_V5_LDS: return launch_v5(c, L, kernel == RM_KERNEL_V5_LDS, n_frames, s);
-    case RM_KERNEL_QUEUE: case RM_KERNEL_QUEUE_LDS: return launch_queue(c, L, kernel == RM_KERNEL_QUEUE_LDS, n_frames, s);
-    case RM_KERNEL_MULTI1: case RM_KERNEL_MULTI1_LDS: return launch_multi<1>(c, L, kernel == RM_KERNEL_MULTI1_LDS, n_frames, s);
-    case RM_KERNEL_MULTI2: case RM_KERNEL_MULTI2_LDS: return launch_multi<2>(c, L, kernel == RM_KERNEL_MULTI2_LDS, n_frames, s);
-    case RM_KERNEL_MULTI4: case RM_KERNEL_MULTI4_LDS: return launch_multi<4>(c, L, kernel == RM_KERNEL_MULTI4_LDS, n_frames, s);
-    default:
-        return fail(c, RM_ERR_ARG, "kernel variant %d is not available", kernel);
     }
     if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
@@ -598,6 +542,21 @@ hipStream_t user_stream(const rm_ctx* c, void* stream) {
     return stream == RM_STREAM_OWN ? c->stream : static_cast<hipStream_t>(stream);
 }
 
+// See rm_ctx::last_stream.  Nothing is issued while consecutive draws stay on one stream (the steady state, and the
+// only state during stream capture).  A previous stream that no longer exists, or that is still being captured (its
+// draws have not run and cannot race), makes the record fail: there is nothing to wait for then.
+void order_with_previous(rm_ctx* c, hipStream_t s) {
+    if (c->last_stream_valid && c->last_stream != s) {
+        if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
+            if (hipStreamWaitEvent(s, c->ev_order, 0) != hipSuccess) (void)hipGetLastError();
+        } else {
+            (void)hipGetLastError();
+        }
+    }
+    c->last_stream = s;
+    c->last_stream_valid = true;
+}
+
 size_t pixel_bytes(const rm_ctx* c) { return c->out_format == RM_FORMAT_RGBA32F ? 16u : 4u; }
 
 int ensure_out(rm_ctx* c, size_t bytes) {
@@ -639,6 +598,7 @@ RM_EXPORT int rm_create(int device, rm_ctx** out) {
     }
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_order, hipEventDisableTiming);
     if (e != hipSuccess) {
         int rc = fail(nullptr, RM_ERR_DEVICE, "rm_create: HIP initialisation failed: %s", hipGetErrorString(e));
         rm_destroy(c);
@@ -670,6 +630,7 @@ RM_EXPORT void rm_destroy(rm_ctx* c) {
     for (auto& e : c->tev) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_order) (void)hipEventDestroy(c->ev_order);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -775,6 +736,7 @@ RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
+    order_with_previous(c, s);
     rc = ensure_program(c, s);
     if (rc == RM_OK) rc = ensure_materials(c, s);
     if (rc != RM_OK) return rc;
@@ -816,6 +778,7 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     if (rows == 0u) return RM_OK;  // more ranks than strips: nothing to do for this one
     if (!out_rgba) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rgba is NULL");
     HIP_TRY(c, hipSetDevice(c->device));
+    order_with_previous(c, out_is_device ? user_stream(c, stream) : c->stream);
     rc = ensure_program(c, out_is_device ? user_stream(c, stream) : c->stream);
     if (rc == RM_OK) rc = ensure_materials(c, out_is_device ? user_stream(c, stream) : c->stream);
     if (rc != RM_OK) return rc;
@@ -834,6 +797,54 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     return RM_OK;
 }
 
+// The final host-side gather of a tiled frame (north-star): this GPU's strips go from the compact device
+// buffer rm_draw_strips filled to their rows of the full H-row host image, one D2H copy per strip on `stream`.
+RM_EXPORT int rm_gather_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,
+                               const void* strips_device, void* host_image, void* stream) {
+    if (!c) return RM_ERR_NULL;
+    int rc = check_dims(c, W, H, 0, H);
+    if (rc != RM_OK) return rc;
+    if (strip_rows == 0u || (strip_rows % 16u) != 0u || stride == 0u || first >= stride)
+        return fail(c, RM_ERR_ARG, "rm_gather_strips: strip_rows %u must be a positive multiple of 16, first %u < stride %u",
+                    strip_rows, first, stride);
+    const uint32_t n_strips = (H + strip_rows - 1u) / strip_rows;
+    if (first >= n_strips) return RM_OK;  // this GPU has no strip
+    if (!strips_device || !host_image) return fail(c, RM_ERR_NULL, "rm_gather_strips: NULL buffer");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipStream_t s = user_stream(c, stream);
+    const size_t row_bytes = (size_t)W * pixel_bytes(c);
+    const uint8_t* src = static_cast<const uint8_t*>(strips_device);
+    uint8_t* dst = static_cast<uint8_t*>(host_image);
+    if (stride == 1u) {  // one GPU: the compact buffer IS the frame
+        HIP_TRY(c, hipMemcpyAsync(dst, src, row_bytes * H, hipMemcpyDeviceToHost, s));
+        return RM_OK;
+    }
+    for (uint32_t sidx = first; sidx < n_strips; sidx += stride) {
+        const uint32_t r0 = sidx * strip_rows, rows = H - r0 < strip_rows ? H - r0 : strip_rows;
+        HIP_TRY(c, hipMemcpyAsync(dst + row_bytes * r0, src, row_bytes * rows, hipMemcpyDeviceToHost, s));
+        src += row_bytes * rows;
+    }
+    return RM_OK;
+}
+
+RM_EXPORT int rm_host_register(void* ptr, uint64_t bytes) {
+    if (!ptr || !bytes) return RM_ERR_NULL;
+    if (hipHostRegister(ptr, bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return RM_ERR_DEVICE;
+    }
+    return RM_OK;
+}
+
+RM_EXPORT int rm_host_unregister(void* ptr) {
+    if (!ptr) return RM_ERR_NULL;
+    if (hipHostUnregister(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return RM_ERR_DEVICE;
+    }
+    return RM_OK;
+}
+
 RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_frames, uint32_t W, uint32_t H,
                             float* out_rgba, int out_is_device, void* stream) {
     if (!c) return RM_ERR_NULL;
@@ -843,6 +854,7 @@ RM_EXPORT int rm_draw_batch(rm_ctx* c, const rm_uniforms* frames, uint32_t n_fra
     if (rc != RM_OK) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = out_is_device ? user_stream(c, stream) : c->stream;
+    order_with_previous(c, s);
     rc = ensure_program(c, s);
     if (rc == RM_OK) rc = ensure_materials(c, s);
     if (rc != RM_OK) return rc;
@@ -886,7 +898,8 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
     if (!c) return RM_ERR_NULL;
     switch (key) {
     case RM_OPT_KERNEL:
-        if (value < RM_KERNEL_DEFAULT || value > RM_KERNEL_V5_LDS) return fail(c, RM_ERR_ARG, "unknown kernel %lld", (long long)value);
+        if (value != RM_KERNEL_DEFAULT && value != RM_KERNEL_PIXEL && value != RM_KERNEL_V5 && value != RM_KERNEL_V5_LDS)
+            return fail(c, RM_ERR_ARG, "unknown kernel %lld (the v2-v4 variants 2..11 of ABI version 1 are retired)", (long long)value);
         c->kernel = (int)value;
         return RM_OK;
     case RM_OPT_TIMING: c->timing = value != 0; c->tev_used = 0; return RM_OK;
@@ -913,7 +926,6 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
         return RM_OK;
     case RM_OPT_REFILL_MIN:
         if (value < 1 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [1,64]", (long long)value);
-        c->refill_min = (uint32_t)value;
         c->refill_min_v5 = (uint32_t)value;
         return RM_OK;
     default: return fail(c, RM_ERR_ARG, "unknown option %d", key);

@@ -1,0 +1,381 @@
+// rm_interp.h -- the interpreter half of the march kernels: exact SDF leaf functions, the accumulator
+// machine that executes a decoded program record by record (map_scene, wgsl:187-203), the material walk,
+// and the arithmetic self-tests.  Device code only (gfx950, wave64).
+//
+// Bit-exactness: every value goes through exactly the operation sequence of the arithmetic
+// contract; only the correctly-rounded sqrt is computed by a shorter (still exact) sequence:
+// see sqrt_rn_fast.
+#pragma once
+#include "rm_kernels.h"
+
+namespace rmk {
+
+// v_min_f32 / v_max_f32 issued directly: the builtins make the compiler insert a canonicalising
+// v_max_f32 x,x in front of every operand it cannot prove quiet (values that went through a
+// phi or LDS), which costs two extra VALU per CSG operator.  Semantics are identical for every
+// non-signalling input (IEEE mode is on; -0 < +0; a quiet NaN operand loses); a SIGNALLING NaN
+// operand would yield a quiet NaN instead of the other operand, but these are only ever applied to
+// results of arithmetic instructions (SDF values, accumulators), which are never signalling
+// (tests/test_gpu_arithmetic.py checks both facts).
+RM_DEV float vmin(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+RM_DEV float vmax_negb(float a, float b) {  // max(a, -b)
+    float r;
+    asm("v_max_f32 %0, %1, -%2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+// Correctly rounded sqrt in v_rsq_f32 + 4 VALU:  y = rsq(x); g = x y; s = g + (x - g g) (y / 2), the residual and
+// the final sum each one FMA.  v_rsq_f32 is a 1-ulp approximation, g is within ~1.5 ulp of sqrt(x), the residual
+// x - g g is exact, and the rounding of the final FMA lands on the correctly rounded root for EVERY binary32 x in
+// [2^-102, FLT_MAX]: established by exhaustion on MI355X (tools/probe_sqrt_range.hip; rm_selftest_sqrt repeats it
+// on whatever GPU the library runs on), not by a proof.  It replaces v_sqrt_f32 + the 8-instruction neighbour test
+// of LLVM's expansion (which this file used before: 9 VALU + v_sqrt_f32).  Outside that range -- 0, inf, NaN,
+// denormals -- the sequence returns NaN or garbage: the caller tracks the range of all arguments of one map_scene
+// evaluation in a SqrtGuard and re-evaluates with __builtin_sqrtf when any lane saw an argument outside
+// [2^-96, FLT_MAX].  Zero is a legitimate and frequent argument for boxes (inside the slab), so ZERO_OK clamps the
+// v_rsq input (g = 0 * y = 0, residual 0, result +0) and keeps zero out of the guard; spheres hit zero only at
+// their exact centre and take the slow path there.
+struct SqrtGuard {
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;  // min / max over the (biased) bit patterns of all sqrt arguments
+    RM_DEV bool bad() const { return lo < kLoBits || hi > 0x7F7FFFFFu; }
+    static constexpr uint32_t kLoBits = 0x0F800000u - 1u;  // bits(2^-96) - 1
+};
+RM_DEV float vmax(float a, float b) {  // direct v_max_f32, see vmin
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+template <bool ZERO_OK>
+RM_DEV float sqrt_rn_fast(float x) {
+    const float y = __builtin_amdgcn_rsqf(ZERO_OK ? vmax(x, __uint_as_float(0x0F800000u)) : x);
+    const float g = x * y, h = 0.5f * y;
+    return __builtin_fmaf(__builtin_fmaf(-g, g, x), h, g);
+}
+
+template <bool FAST, bool ZERO_OK = false>
+RM_DEV float sqrt_sel(float x, SqrtGuard& guard) {
+    if constexpr (FAST) {
+        // x >= +0 or NaN here (sums of squares).  ZERO_OK: (bits - 1) wraps 0 to the top, so only 0 < x < 2^-96 is low.
+        guard.lo = min(guard.lo, ZERO_OK ? __float_as_uint(x) - 1u : __float_as_uint(x));
+        guard.hi = max(guard.hi, __float_as_uint(x));
+        return sqrt_rn_fast<ZERO_OK>(x);
+    } else {
+        return __builtin_sqrtf(x);
+    }
+}
+
+template <bool FAST>
+RM_DEV float sdf_sphere_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
+    const float dx = px - p[0], dy = py - p[1], dz = pz - p[2];
+    return sqrt_sel<FAST>((dx * dx + dy * dy) + dz * dz, tiny) - p[3];
+}
+template <bool FAST>
+RM_DEV float sdf_box_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
+    const float qx = __builtin_fabsf(px - p[0]) - p[3];
+    const float qy = __builtin_fabsf(py - p[1]) - p[4];
+    const float qz = __builtin_fabsf(pz - p[2]) - p[5];
+    const float mx = fmax_(qx, 0.0f), my = fmax_(qy, 0.0f), mz = fmax_(qz, 0.0f);
+    return sqrt_sel<FAST, true>((mx * mx + my * my) + mz * mz, tiny) + fmin_(fmax_(qx, fmax_(qy, qz)), 0.0f);
+}
+
+template <bool FAST>
+RM_DEV float sdf_cylinder_t(float px, float py, float pz, const float (&p)[7], SqrtGuard& tiny) {
+    // extension: capped cylinder along y.  p = cx cy cz radius half_height
+    const float dx = px - p[0], dz = pz - p[2];
+    const float qx = sqrt_sel<FAST, true>(dx * dx + dz * dz, tiny) - p[3];
+    const float qy = __builtin_fabsf(py - p[1]) - p[4];
+    const float mx = fmax_(qx, 0.0f), my = fmax_(qy, 0.0f);
+    return fmin_(fmax_(qx, qy), 0.0f) + sqrt_sel<FAST, true>(mx * mx + my * my, tiny);
+}
+
+// Space transformations (extension; semantics: oracle/rm_oracle.c map_scene, opcodes 200-205).  Every product and
+// difference is one binary32 operation, in the oracle's order.
+RM_DEV void xf_rotate_conj(float w, float ax, float ay, float az, float& x, float& y, float& z) {
+    const float cx = y * az - z * ay, cy = z * ax - x * az, cz = x * ay - y * ax;  // p x a = (-a) x p
+    const float tx = 2.0f * cx, ty = 2.0f * cy, tz = 2.0f * cz;
+    const float ux = ty * az - tz * ay, uy = tz * ax - tx * az, uz = tx * ay - ty * ax;  // t x a
+    x = (x + w * tx) + ux;
+    y = (y + w * ty) + uy;
+    z = (z + w * tz) + uz;
+}
+
+// One decoded command applied to the R positions of a lane.
+// EXT = false compiles the reference's four node types only (the lean, measured path); EXT = true
+// adds the extension node types.  Which one runs is decided per program on the host.
+template <int R, bool FAST, bool EXT = false>
+RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float (&qy)[R], float (&qz)[R], float (&acc)[R],
+                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u) {
+    // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
+    // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
+    // wait for the NEXT record's LDS read before starting the current record's arithmetic.
+    op = __builtin_amdgcn_readfirstlane(op);
+    const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
+    if constexpr (EXT) {
+        if (kind == RM_KIND_XFORM) {  // extension: the evaluation position changes; saved positions live in LDS
+            float* save = spill + (size_t)(xf_base + 3u * __float_as_uint(p[6])) * R * 64u;
+#pragma unroll
+            for (int k = 0; k < R; k++) {
+                if ((mode & 1u) == 0u) {  // push
+                    save[(0 * R + k) * 64] = qx[k]; save[(1 * R + k) * 64] = qy[k]; save[(2 * R + k) * 64] = qz[k];
+                    if (mode == RM_XF_T_PUSH) { qx[k] = qx[k] - p[0]; qy[k] = qy[k] - p[1]; qz[k] = qz[k] - p[2]; }
+                    else if (mode == RM_XF_R_PUSH) xf_rotate_conj(p[0], p[1], p[2], p[3], qx[k], qy[k], qz[k]);
+                    else { qx[k] = qx[k] / p[0]; qy[k] = qy[k] / p[0]; qz[k] = qz[k] / p[0]; }
+                } else {  // pop
+                    qx[k] = save[(0 * R + k) * 64]; qy[k] = save[(1 * R + k) * 64]; qz[k] = save[(2 * R + k) * 64];
+                    if (mode == RM_XF_S_POP) acc[k] = acc[k] * p[0];
+                }
+            }
+            return;
+        }
+    }
+    float a[R], b[R];
+    if (kind == RM_KIND_POP) {
+        --sp;
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            b[k] = acc[k];
+            a[k] = spill[(sp * R + k) * 64u];
+        }
+    } else {
+        if (kind == RM_KIND_SPHERE) {
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+        } else if (!EXT || kind == RM_KIND_BOX) {
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = sdf_box_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+        } else if (kind == RM_KIND_CYLINDER) {  // extension
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = sdf_cylinder_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+        } else {  // RM_KIND_PLANE, extension: dot(pos, n) + h
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = ((qx[k] * p[0] + qy[k] * p[1]) + qz[k] * p[2]) + p[3];
+        }
+        if (op & RM_OP_SPILL) {
+#pragma unroll
+            for (int k = 0; k < R; k++) spill[(sp * R + k) * 64u] = acc[k];
+            ++sp;
+        }
+#pragma unroll
+        for (int k = 0; k < R; k++) a[k] = acc[k];
+    }
+    if (mode == RM_MODE_PUSH) {
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = b[k];
+    } else if (mode == RM_MODE_UNION) {
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = vmin(a[k], b[k]);  // wgsl:242-246
+    } else if (!EXT || mode == RM_MODE_SUB) {
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = vmax_negb(a[k], b[k]);  // wgsl:248-252
+    } else if (mode == RM_MODE_INTER) {  // extension: max(a, b)
+#pragma unroll
+        for (int k = 0; k < R; k++) acc[k] = fmax_(a[k], b[k]);
+    } else {  // RM_MODE_SMOOTH, extension: min(a,b) - h*h*k/4, h = max(k - |a-b|, 0)/k; k <= 0: plain min
+        const float kk = p[0];
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            float v = fmin_(a[k], b[k]);
+            if (kk > 0.0f) {
+                const float h = fmax_(kk - __builtin_fabsf(a[k] - b[k]), 0.0f) / kk;
+                v = v - ((h * h) * kk) * 0.25f;
+            }
+            acc[k] = v;
+        }
+    }
+}
+
+// map_scene (wgsl:187-203) for R positions per lane.  Commands are fetched one ahead of their
+// use (two buffers, loop unrolled by two) so that the fetch latency hides behind the VALU work
+// of the previous command.
+template <int R, bool FAST, class Prog, bool EXT = false>
+RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx_in)[R],
+                            const float (&qy_in)[R], const float (&qz_in)[R], float (&out)[R], SqrtGuard& tiny,
+                            uint32_t xf_base = 0u) {
+    float qx[R], qy[R], qz[R];  // transform commands (EXT) change the evaluation position
+#pragma unroll
+    for (int k = 0; k < R; k++) { qx[k] = qx_in[k]; qy[k] = qy_in[k]; qz[k] = qz_in[k]; }
+    if (n_rec == 0u) {  // wgsl:189-191
+#pragma unroll
+        for (int k = 0; k < R; k++) out[k] = max_dist;
+        return;
+    }
+    float acc[R];
+#pragma unroll
+    for (int k = 0; k < R; k++) acc[k] = 0.0f;
+    uint32_t sp = 0, c = 0;
+#ifdef RM_SIMPLE_LOOP
+    for (; c < n_rec; c++) {
+        uint32_t op0;
+        float p0[7];
+        prog.load(c, op0, p0);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+    }
+#else
+    uint32_t op0, op1;
+    float p0[7], p1[7];
+    prog.load(0u, op0, p0);
+    for (;;) {
+        prog.load(c + 1u < n_rec ? c + 1u : c, op1, p1);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+        if (++c == n_rec) break;
+        prog.load(c + 1u < n_rec ? c + 1u : c, op0, p0);
+        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+        if (++c == n_rec) break;
+    }
+#endif
+#pragma unroll
+    for (int k = 0; k < R; k++) out[k] = acc[k];
+}
+
+// Materials (extension; semantics: oracle/rm_oracle.c map_scene_impl with mat_out).  One evaluation of the material
+// program (RmLaunch::mprog: the program decoded with its Material tags in place) at the position of a hit, on a stack
+// of (distance, index) pairs: the accumulator pair lives in registers, deeper pairs in the wave's LDS spill area
+// ([depth] distances, then [depth] indices, then 3 floats per transform level; `spill` already points at this lane).
+// Runs once per hit ray against tens of march steps, so it is a plain loop with the generic (correctly rounded)
+// square root; the distances are the ones map_scene computes at this point, operation for operation.
+RM_DEV uint32_t map_scene_material(const RmRecord* __restrict__ mprog, uint32_t n_mrec, float* spill, uint32_t value_depth,
+                                   float x, float y, float z) {
+    float acc = 0.0f;
+    uint32_t accm = 0u, sp = 0u;
+    uint32_t* mspill = reinterpret_cast<uint32_t*>(spill) + (size_t)value_depth * 64u;
+    float* saved = spill + (size_t)2u * value_depth * 64u;
+    SqrtGuard unused;
+    for (uint32_t c = 0; c < n_mrec; c++) {
+        const RmRecord& r = mprog[c];  // wave-uniform address: scalar loads
+        const uint32_t op = r.op, kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
+        float p[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) p[k] = r.p[k];
+        if (kind == RM_KIND_MATERIAL) {
+            accm = __float_as_uint(p[0]);
+            continue;
+        }
+        if (kind == RM_KIND_XFORM) {
+            float* save = saved + (size_t)3u * __float_as_uint(p[6]) * 64u;
+            if ((mode & 1u) == 0u) {
+                save[0] = x; save[64] = y; save[128] = z;
+                if (mode == RM_XF_T_PUSH) { x = x - p[0]; y = y - p[1]; z = z - p[2]; }
+                else if (mode == RM_XF_R_PUSH) xf_rotate_conj(p[0], p[1], p[2], p[3], x, y, z);
+                else { x = x / p[0]; y = y / p[0]; z = z / p[0]; }
+            } else {
+                x = save[0]; y = save[64]; z = save[128];
+                if (mode == RM_XF_S_POP) acc = acc * p[0];
+            }
+            continue;
+        }
+        float a, b;
+        uint32_t am, bm;
+        if (kind == RM_KIND_POP) {
+            --sp;
+            b = acc; bm = accm;
+            a = spill[sp * 64u]; am = mspill[sp * 64u];
+        } else {
+            if (kind == RM_KIND_SPHERE) b = sdf_sphere_t<false>(x, y, z, p, unused);
+            else if (kind == RM_KIND_BOX) b = sdf_box_t<false>(x, y, z, p, unused);
+            else if (kind == RM_KIND_CYLINDER) b = sdf_cylinder_t<false>(x, y, z, p, unused);
+            else b = ((x * p[0] + y * p[1]) + z * p[2]) + p[3];
+            bm = 0u;
+            if (op & RM_OP_SPILL) {
+                spill[sp * 64u] = acc; mspill[sp * 64u] = accm;
+                ++sp;
+            }
+            a = acc; am = accm;
+        }
+        if (mode == RM_MODE_PUSH) {
+            acc = b; accm = bm;
+        } else if (mode == RM_MODE_UNION) {
+            acc = vmin(a, b); accm = b < a ? bm : am;
+        } else if (mode == RM_MODE_SUB) {
+            acc = vmax_negb(a, b); accm = -b > a ? bm : am;
+        } else if (mode == RM_MODE_INTER) {
+            acc = fmax_(a, b); accm = b > a ? bm : am;
+        } else {  // RM_MODE_SMOOTH
+            const float kk = p[0];
+            float v = fmin_(a, b);
+            if (kk > 0.0f) {
+                const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) / kk;
+                v = v - ((h * h) * kk) * 0.25f;
+            }
+            acc = v; accm = b < a ? bm : am;
+        }
+    }
+    return accm;
+}
+
+// The shader's ray direction is the .xyz of a normalised vec4 (wgsl:62): whenever the w components of
+// pt_world and ro differ (any projection with znear != 1) it is SHORTER than 1, and the march walks the
+// half-line along d / |d|.  The miss tests are statements about that half-line, so they use the unit
+// direction; a zero or non-finite d gives NaN here and every comparison below then says "not clear".
+RM_DEV void unit_dir(float& dx, float& dy, float& dz) {
+    const float inv = __builtin_amdgcn_rsqf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+    dx *= inv; dy *= inv; dz *= inv;  // |error| ~1e-7, far inside the 1e-5 slack of the table entries
+}
+// One-float result code of a ray that did not hit (see the resolve step).
+RM_DEV float miss_code(const V4& ro, float dx, float dy, float dz) {
+    const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);
+    return c < 0 ? -3.0f : -1.0f - (float)c;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Self-tests of the arithmetic building blocks (diagnostics, rm_selftest_* in the ABI).
+// ---------------------------------------------------------------------------------------------
+// Exhaustive: for EVERY binary32 bit pattern x >= +0 (what a sum of squares can be) and both forms of the guarded
+// fast sqrt, either the guard sends the evaluation to the generic path or the result is the correctly rounded root.
+// Also counts the in-range inputs the guard rejects: must be none besides 0 for the ZERO_OK = false form.
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
+__global__ __launch_bounds__(256) void rm_selftest_sqrt_kernel(uint32_t first, uint64_t count, unsigned long long* mismatches,
+                                                               uint32_t* first_bad) {
+    const uint64_t stride = (uint64_t)gridDim.x * 256u;
+    unsigned long long bad = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < count; i += stride) {
+        const uint32_t bits = first + (uint32_t)i;
+        if (bits > 0x7FFFFFFFu && bits != 0xFFC00000u) continue;  // negative: never an argument (one NaN with the sign set stays in)
+        const float x = __uint_as_float(bits);
+        const float want = __builtin_sqrtf(x);
+        const bool in_range = bits >= 0x0F800000u && bits <= 0x7F7FFFFFu;
+        bool ok = true;
+        {
+            SqrtGuard g;
+            const float a = sqrt_sel<true, false>(x, g);
+            ok = ok && (g.bad() ? !in_range : __float_as_uint(a) == __float_as_uint(want));
+        }
+        {
+            SqrtGuard g;
+            const float a = sqrt_sel<true, true>(x, g);
+            ok = ok && (g.bad() ? !(in_range || bits == 0u) : __float_as_uint(a) == __float_as_uint(want));
+        }
+        if (!ok) {
+            bad++;
+            atomicMin(first_bad, bits);
+        }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+#endif
+
+// Element-wise results of the primitives the kernels rely on, for comparison with the oracle's
+// definitions on the host: out[0..7][i] = min, max, direct v_min, direct v_max(a,-b), fast sqrt(a),
+// generic sqrt(a), a / b, (float) i32(round(a)).
+#if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
+__global__ __launch_bounds__(256) void rm_selftest_ops_kernel(const float* a, const float* b, float* out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const float x = a[i], y = b[i];
+    out[0u * n + i] = fmin_(x, y);
+    out[1u * n + i] = fmax_(x, y);
+    out[2u * n + i] = vmin(x, y);
+    out[3u * n + i] = vmax_negb(x, y);
+    SqrtGuard guard;
+    const float fast = sqrt_sel<true, true>(x, guard);  // what a kernel does: fast form unless the guard objects
+    out[4u * n + i] = guard.bad() ? __builtin_sqrtf(x) : fast;
+    out[5u * n + i] = __builtin_sqrtf(x);
+    out[6u * n + i] = x / y;
+    out[7u * n + i] = (float)__float2int_rz(__builtin_rintf(x));
+}
+#endif
+
+}  // namespace rmk

@@ -117,7 +117,7 @@ inline std::string structure_key(const std::vector<RmRecord>& rec) {
 
 inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty() && rec.size() <= kMaxRecords; }
 
-// Straight-line map_scene for `rec`, mirroring exec_command (rm_kernel_multi.h) record by record
+// Straight-line map_scene for `rec`, mirroring exec_command (rm_interp.h) record by record
 // with the value stack resolved at generation time: the accumulator and every spilled value become
 // named values.  With `prune`, sphere and box leaves are wrapped in the wave-uniform far test of
 // rm_kernel_v5.h ("Pruning").  Returns false if the records do not form a valid program (cannot
@@ -436,48 +436,77 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     return true;
 }
 
-// Compile `src` for gfx950.  No HIP runtime call is made: this runs on worker threads and on
-// machines without a GPU (the build check).
-inline bool compile(const std::string& src, std::vector<char>* code, std::string* log, double* ms) {
+// Disk-cache file (RM_JIT_CACHE_DIR): a 32-byte header in front of the code object, so that a truncated or corrupt
+// file is recognised when it is read and not when hipModuleLoadData chokes on it.
+struct CacheHeader {
+    char magic[8];       // "RMJITCO\1"
+    uint64_t bytes;      // length of the code object that follows
+    uint64_t checksum;   // FNV-1a of those bytes
+    uint64_t reserved;
+};
+inline uint64_t fnv1a(const char* p, size_t n, uint64_t h = 1469598103934665603ull) {
+    for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
+inline const char* const* compile_options(int* n) {
+    // the flags of the offline build (build.py HIP_FLAGS) that affect code generation
+    static const char* const opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    *n = (int)(sizeof opts / sizeof *opts);
+    return opts;
+}
+// Where the code object of `src` lives in the disk cache ("" when the cache is off): keyed by everything that
+// determines it -- the generated source, the embedded headers, the compile options, the compiler (file + version).
+inline std::string cache_path(const std::string& src) {
+    const char* dir = std::getenv("RM_JIT_CACHE_DIR");
     Rtc& rtc = Rtc::get();
+    if (!dir || !rtc.ok()) return std::string();
+    uint64_t h = fnv1a(src.data(), src.size());
+    for (int i = 0; i < kNumHeaders; i++) h = fnv1a(kHeaderSources[i], std::strlen(kHeaderSources[i]), h);
+    int n_opts = 0;
+    const char* const* opts = compile_options(&n_opts);
+    for (int i = 0; i < n_opts; i++) h = fnv1a(opts[i], std::strlen(opts[i]) + 1, h);
+    h = fnv1a(rtc.identity.data(), rtc.identity.size(), h);
+    char name[64];
+    std::snprintf(name, sizeof name, "/rm_%016llx.co", (unsigned long long)h);
+    return std::string(dir) + name;
+}
+
+// Compile `src` for gfx950.  No HIP runtime call is made: this runs on worker threads and on
+// machines without a GPU (the build check).  *from_cache (nullable) says whether the code came from the disk cache.
+inline bool compile(const std::string& src, std::vector<char>* code, std::string* log, double* ms, bool* from_cache = nullptr) {
+    Rtc& rtc = Rtc::get();
+    if (from_cache) *from_cache = false;
     if (!rtc.ok()) { *log = rtc.error; return false; }
     const auto t0 = std::chrono::steady_clock::now();
-    // Optional disk cache (RM_JIT_CACHE_DIR): code objects keyed by everything that determines them -- the generated
-    // source, the embedded headers, the compiler (library file + version).  A second process starts warm.
-    std::string cache_file;
-    if (const char* dir = std::getenv("RM_JIT_CACHE_DIR")) {
-        uint64_t h = 1469598103934665603ull;
-        auto mix = [&](const char* p, size_t n) { for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; } };
-        mix(src.data(), src.size());
-        for (int i = 0; i < kNumHeaders; i++) mix(kHeaderSources[i], std::strlen(kHeaderSources[i]));
-        mix(rtc.identity.data(), rtc.identity.size());
-        char name[64];
-        std::snprintf(name, sizeof name, "/rm_%016llx.co", (unsigned long long)h);
-        cache_file = std::string(dir) + name;
+    // Optional disk cache (RM_JIT_CACHE_DIR): a second process starts warm.
+    const std::string cache_file = cache_path(src);
+    if (!cache_file.empty()) {
         if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
-            std::fseek(f, 0, SEEK_END);
-            const long n = std::ftell(f);
-            std::fseek(f, 0, SEEK_SET);
-            bool ok = n > 64;
+            CacheHeader hd;
+            bool ok = std::fread(&hd, 1, sizeof hd, f) == sizeof hd && std::memcmp(hd.magic, "RMJITCO\1", 8) == 0 &&
+                      hd.bytes > 64 && hd.bytes < (1ull << 30);
             if (ok) {
-                code->resize((size_t)n);
-                ok = std::fread(code->data(), 1, (size_t)n, f) == (size_t)n && std::memcmp(code->data(), "\177ELF", 4) == 0;
+                code->resize((size_t)hd.bytes);
+                ok = std::fread(code->data(), 1, code->size(), f) == code->size() && std::fgetc(f) == EOF &&
+                     std::memcmp(code->data(), "\177ELF", 4) == 0 && fnv1a(code->data(), code->size()) == hd.checksum;
             }
             std::fclose(f);
             if (ok) {
                 *log = "loaded from " + cache_file;
+                if (from_cache) *from_cache = true;
                 if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
                 return true;
             }
             code->clear();
+            std::remove(cache_file.c_str());  // truncated or corrupt: it is rewritten below
         }
     }
     Rtc::Program prog = nullptr;
     int rc = rtc.CreateProgram(&prog, src.c_str(), "rm_spec.hip", (int)kNumHeaders, kHeaderSources, kHeaderNames);
     if (rc != 0) { *log = "hiprtcCreateProgram failed: " + std::to_string(rc); return false; }
-    // the flags of the offline build (build.py HIP_FLAGS) that affect code generation
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
-    rc = rtc.CompileProgram(prog, (int)(sizeof opts / sizeof *opts), opts);
+    int n_opts = 0;
+    const char* const* opts = compile_options(&n_opts);
+    rc = rtc.CompileProgram(prog, n_opts, opts);
     size_t n = 0;
     if (rtc.GetProgramLogSize(prog, &n) == 0 && n > 1) {
         log->resize(n);
@@ -498,9 +527,14 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
     if (ok && !cache_file.empty()) {  // write-then-rename: another process never sees half a file
         const std::string tmp = cache_file + ".part" + std::to_string((long)getpid());
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
-            const bool w = std::fwrite(code->data(), 1, code->size(), f) == code->size();
-            std::fclose(f);
-            if (!w || std::rename(tmp.c_str(), cache_file.c_str()) != 0) std::remove(tmp.c_str());
+            CacheHeader hd;
+            std::memset(&hd, 0, sizeof hd);
+            std::memcpy(hd.magic, "RMJITCO\1", 8);
+            hd.bytes = code->size();
+            hd.checksum = fnv1a(code->data(), code->size());
+            const bool w = std::fwrite(&hd, 1, sizeof hd, f) == sizeof hd && std::fwrite(code->data(), 1, code->size(), f) == code->size();
+            const bool closed = std::fclose(f) == 0;
+            if (!w || !closed || std::rename(tmp.c_str(), cache_file.c_str()) != 0) std::remove(tmp.c_str());
         }
     }
     if (const char* dir = std::getenv("RM_JIT_DUMP_DIR")) {  // diagnostics: keep what was compiled
@@ -523,6 +557,8 @@ struct Entry {
     std::vector<char> code;  // gfx950 code object
     std::string log;
     double compile_ms = 0.0;
+    std::string cached_source;  // non-empty iff `code` came from the disk cache: if the loader rejects it, the file is
+                                // dropped and this source compiled afresh, once (rm_abi.hip specialised_kernel)
     // Filled by the caller's (HIP) thread under `m`: device ordinal -> {hipModule_t, hipFunction_t}.
     struct Loaded { void* module = nullptr; void* function = nullptr; };
     std::map<int, Loaded> loaded;
@@ -612,9 +648,11 @@ private:
             std::vector<char> code;
             std::string log;
             double ms = 0.0;
-            const bool ok = compile(job.source, &code, &log, &ms);
+            bool from_cache = false;
+            const bool ok = compile(job.source, &code, &log, &ms, &from_cache);
             {
                 std::lock_guard<std::mutex> g(job.entry->m);
+                if (ok && from_cache) job.entry->cached_source = std::move(job.source);
                 job.entry->code = std::move(code);
                 job.entry->log = std::move(log);
                 job.entry->compile_ms = ms;

@@ -1,7 +1,9 @@
 // rm_kernel_v5.h -- kernel v5 "streamed ray pool" (gfx950, wave64).  Device code only.
 //
-// One workgroup of WPT waves owns an 8x8-pixel tile and the pool of its 1024 rays (as in v3).
-// What changes is WHERE the expensive, branchy per-ray work runs:
+// One workgroup of WPT waves owns an 8x8-pixel tile and the pool of its 1024 rays: a lane marches ONE
+// ray at a time; when its ray ends, the lane is refilled (ballot + prefix count) with the next ray, so
+// every trip through map_scene runs with (nearly) all 64 lanes live whatever the per-ray step counts
+// are.  WHERE the expensive, branchy per-ray work runs:
 //
 //   produce  Ray generation (2 mat-vec + vec4 normalize: wgsl:52-62) and the exact miss test run
 //            for 64 consecutive rays of the pool at a time with ALL lanes active, using scratch
@@ -14,17 +16,18 @@
 //            once, 2 normalizes = 6 correctly rounded divides + 2 sqrt per hit) when the next push
 //            would not fit.
 //
-// In v3 these pieces ran inside the march loop under a sparse exec mask (typically 8-14 of 64
-// lanes) and cost ~25 % of all vector instructions; here they run at (nearly) full occupancy and
-// the march loop is: evaluation point, map_scene, ~20 VALU of state update, three ballots.
+// In the retired v2-v4 kernels (DESIGN.md 5 keeps their numbers) these pieces ran inside the march loop
+// under a sparse exec mask (typically 8-14 of 64 lanes) and cost ~25 % of all vector instructions; here
+// they run at (nearly) full occupancy and the march loop is: evaluation point, map_scene, ~20 VALU of
+// state update, three ballots.
 // Both rings are private to a wave (no barrier; LDS executes a wave's accesses in order), the
 // pool cursor and the result array are shared by the tile's waves.
 //
-// The miss test is also sharper than v3's: boxes use a ray/slab test against the box inflated by
-// the margin instead of a bounding-sphere cone, and the margin is min_dist + 1e-4 of the local
-// coordinate scale (float error of positions and SDF values is ~1e-6 of that scale).
+// Miss test: spheres get a cone test, boxes a ray/slab test against the box inflated by the margin
+// (min_dist + 1e-4 of the local coordinate scale; float error of positions and SDF values is ~1e-6 of
+// that scale).
 #pragma once
-#include "rm_kernel_multi.h"
+#include "rm_interp.h"
 
 namespace rmk {
 

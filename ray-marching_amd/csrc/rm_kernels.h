@@ -248,22 +248,10 @@ __global__ __launch_bounds__(256) void rm_render_pixel(RmLaunch L) {
 }
 #endif
 
-// =============================================================================================
-// Kernel v2 "raypool": one wave (= one 64-thread workgroup) owns an 8x8-pixel tile and the
-// pool of its 64 x 16 = 1024 rays.  A lane marches ONE ray at a time; when its ray ends it
-// parks, and once `refill_min` lanes are parked (ballot + popcount) the wave shades the parked
-// rays, hands every parked lane the next unassigned ray (prefix count of the ballot mask) and
-// generates it.  Every trip through map_scene therefore runs with (nearly) all 64 lanes live,
-// whatever the per-ray step counts are: early-out divergence is compacted away instead of
-// idling lanes until the slowest of 16 lock-step samples finishes.
-//
+// ---- pieces shared by the ray-pool kernels (rm_kernel_v5.h) ---------------------------------
 // Per-sample results are parked in LDS as ONE float each (hit: diffuse intensity k >= 0.02;
 // miss: -1 - checker bit; black: -3) and resolved per pixel in the reference's sample order
 // (i outer, j inner: wgsl:44-45, 68-69), so the sum is bit-identical to the nested loops.
-//
-// LDS per wave: res[16][64] f32 (4 KiB) + pt_screen table [2][64] (512 B) + value-stack
-// spill [depth][64] (+ the decoded program for the LDS policy).
-// =============================================================================================
 enum : uint32_t { M_MARCH = 0, M_TAP0 = 1, M_TAP3 = 4, M_DONE_HIT = 5, M_DONE_MISS = 6, M_EMPTY = 7, M_RETIRED = 8 };
 
 RM_DEV uint32_t lane_rank(unsigned long long mask) {  // number of set bits of `mask` below this lane
@@ -274,143 +262,6 @@ RM_DEV void tap_signs(uint32_t t, uint32_t& sx, uint32_t& sy, uint32_t& sz) {
     sx = ((t ^ (t >> 1)) & 1u) << 31;  // negative for t = 1, 2
     sy = ((~t >> 1) & 1u) << 31;       // negative for t = 0, 1
     sz = (~t & 1u) << 31;              // negative for t = 0, 2
-}
-
-template <class Prog, bool PROG_IN_LDS>
-__global__ __launch_bounds__(64) void rm_render_raypool(RmLaunch L, uint32_t refill_min) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t lane = threadIdx.x;
-    float* res = reinterpret_cast<float*>(smem);  // [16][64]
-    float* sxy = res + 1024;                      // [2][64]
-    float* spill = sxy + 128;                     // [spill_depth][64]
-    uint32_t* lprog = reinterpret_cast<uint32_t*>(spill + L.spill_depth * 64u);
-
-    rm_uniforms u = L.u;
-    if (L.frames) u = L.frames[blockIdx.z];  // wave-uniform
-    float* out = L.out + (size_t)blockIdx.z * L.rows * L.W * 4;
-
-    // This lane's own pixel (edge tiles clamp: the duplicate work is discarded at the store).
-    const uint32_t tx = blockIdx.x * 8u + (lane & 7u), ty = blockIdx.y * 8u + (lane >> 3);
-    const uint32_t px = tx < L.W ? tx : L.W - 1u;
-    const uint32_t ry = ty < L.rows ? ty : L.rows - 1u;
-    sxy[lane] = screen_x(px, L.W);
-    sxy[64u + lane] = screen_y(rm_global_row(L, ry), L.H);
-    if (PROG_IN_LDS) {
-        const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
-        for (uint32_t k = lane; k < L.n_rec * 8u; k += 64u) lprog[k] = src[k];
-    }
-    __syncthreads();
-
-    Prog prog;
-    if constexpr (PROG_IN_LDS) prog.base = lprog;
-    else prog.base = L.prog;
-    const SpillLds st{spill + lane, 64u};
-    const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);  // wgsl:39-40
-    const float eps = 0.0001f;                                    // wgsl:136
-
-    // per-lane ray state: evaluation point = b + d * sc
-    float bx = 0.f, by = 0.f, bz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f;
-    float nx = 0.f, ny = 0.f, nz = 0.f;
-    uint32_t it = 0, mode = M_EMPTY, rid = 0;
-    uint32_t next = 0;  // wave-uniform: first unassigned ray of the pool
-
-    for (;;) {
-        const bool parked = mode >= M_DONE_HIT && mode <= M_EMPTY;
-        const unsigned long long parked_mask = __ballot(parked);
-        const unsigned long long live_mask = __ballot(mode < M_DONE_HIT);
-        const uint32_t n_parked = (uint32_t)__popcll(parked_mask);
-        if (n_parked != 0u && (live_mask == 0ull || (n_parked >= refill_min && next < 1024u))) {
-            if (parked) {
-                // ---- shade the finished ray, park its one-float result ----
-                if (mode == M_DONE_HIT) {
-                    res[rid] = shade_hit(nx, ny, nz, bx, by, bz);  // wgsl:98-103
-                } else if (mode == M_DONE_MISS) {
-                    const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
-                    res[rid] = c < 0 ? -3.0f : -1.0f - (float)c;
-                }
-                // ---- take the next ray of the pool ----
-                const uint32_t r = next + lane_rank(parked_mask);
-                if (r < 1024u) {
-                    rid = r;
-                    const uint32_t p = r & 63u, s = r >> 6;  // sample-major: res[s][p] == res[r]
-                    gen_ray(u, ro, sxy[p], sxy[64u + p], s >> 2, s & 3u, dx, dy, dz);
-                    bx = ro.x; by = ro.y; bz = ro.z;
-                    sc = 0.0f;  // dist (wgsl:88)
-                    it = 0u;
-                    mode = L.max_iter != 0u ? M_MARCH : M_DONE_MISS;
-                } else {
-                    mode = M_RETIRED;
-                }
-            }
-            next = next + n_parked < 2048u ? next + n_parked : 2048u;
-            continue;  // re-evaluate the masks
-        }
-        if (live_mask == 0ull) break;  // every lane retired
-
-        if (mode < M_DONE_HIT) {
-            const float qx = bx + dx * sc, qy = by + dy * sc, qz = bz + dz * sc;  // wgsl:91 / :138-141
-            const float v = map_scene(prog, L.n_rec, st, L.max_dist, qx, qy, qz);
-            if (mode == M_MARCH) {
-                if (v < L.min_dist) {  // wgsl:97: hit -> switch to the normal taps at pos = q
-                    bx = qx; by = qy; bz = qz;
-                    sc = eps;
-                    uint32_t sx, sy, sz;
-                    tap_signs(0u, sx, sy, sz);
-                    dx = __uint_as_float(0x3F800000u ^ sx);
-                    dy = __uint_as_float(0x3F800000u ^ sy);
-                    dz = __uint_as_float(0x3F800000u ^ sz);
-                    mode = M_TAP0;
-                } else if (v > L.max_dist) {  // wgsl:109-111
-                    mode = M_DONE_MISS;
-                } else {
-                    sc += v;  // wgsl:114
-                    it += 1u;
-                    if (it >= L.max_iter) mode = M_DONE_MISS;  // loop bound, wgsl:90
-                }
-            } else {
-                // tap t: n (+)= k_t * f   (products with +-1 are exact: flip the sign bit)
-                const uint32_t t = mode - M_TAP0;
-                uint32_t sx, sy, sz;
-                tap_signs(t, sx, sy, sz);
-                const float vx = __uint_as_float(__float_as_uint(v) ^ sx);
-                const float vy = __uint_as_float(__float_as_uint(v) ^ sy);
-                const float vz = __uint_as_float(__float_as_uint(v) ^ sz);
-                nx = t == 0u ? vx : nx + vx;
-                ny = t == 0u ? vy : ny + vy;
-                nz = t == 0u ? vz : nz + vz;
-                tap_signs(t + 1u, sx, sy, sz);
-                dx = __uint_as_float(0x3F800000u ^ sx);
-                dy = __uint_as_float(0x3F800000u ^ sy);
-                dz = __uint_as_float(0x3F800000u ^ sz);
-                mode += 1u;  // M_TAP3 + 1 == M_DONE_HIT
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- resolve: this lane's pixel, samples in the reference order ----
-    if (tx < L.W && ty < L.rows) {
-        float tr = 0.0f, tg = 0.0f, tb = 0.0f;
-#pragma unroll 4
-        for (uint32_t s = 0; s < 16u; s++) {
-            const float code = res[s * 64u + lane];
-            float cr, cg, cb;
-            if (code >= 0.0f) {  // hit: (0.4,0.7,0.1) * k  (wgsl:105)
-                cr = 0.4f * code; cg = 0.7f * code; cb = 0.1f * code;
-            } else if (code > -2.5f) {  // floor (wgsl:127)
-                const float g = 0.2f * (-1.0f - code);
-                cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
-            } else {
-                cr = 0.0f; cg = 0.0f; cb = 0.0f;  // wgsl:130
-            }
-            tr += __builtin_sqrtf(cr);  // wgsl:68-69
-            tg += __builtin_sqrtf(cg);
-            tb += __builtin_sqrtf(cb);
-        }
-        float4 o;
-        o.x = tr / 16.0f; o.y = tg / 16.0f; o.z = tb / 16.0f; o.w = 1.0f;  // wgsl:73-75
-        reinterpret_cast<float4*>(out)[(size_t)ty * L.W + tx] = o;
-    }
 }
 
 // Stream-write calibration kernel: 16 B per lane, grid-stride.

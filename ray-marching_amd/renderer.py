@@ -119,6 +119,12 @@ class RayMarchingResources:
                                            C.c_void_p(stream) if stream else None, C.byref(n)))
         return n.value
 
+    def gather_strips(self, W, H, strip_rows, first, stride, strips_ptr, host_ptr, stream=None):
+        """rm_gather_strips: this GPU's strips (device buffer rm_draw_strips filled) -> their rows of the full host image
+        at address host_ptr (pinned / registered memory: asynchronous on `stream`)."""
+        self._check(self._L.rm_gather_strips(self._h, W, H, strip_rows, first, stride, C.c_void_p(strips_ptr),
+                                             C.c_void_p(host_ptr), C.c_void_p(stream) if stream else None))
+
     def draw_batch(self, frames, W, H):
         arr = (Uniforms * len(frames))(*frames)
         out = np.empty((len(frames), H, W, 4), dtype=self._dtype)

@@ -69,20 +69,31 @@ def gather_image(compact, W, H, rank, world, strip_rows=DEFAULT_STRIP_ROWS, grou
 
 class SharedImage:
     """One (H, W, 4) image in POSIX shared memory that every rank of the node maps: the host-side gather of a tiled
-    frame becomes "each rank copies its own strips to their place" plus a barrier -- no rank relays another rank's
-    pixels (gather_image moves every strip twice and serialises on the destination).  Rank `dst` creates the segment,
-    the others attach after the barrier in open(); close() unlinks it on `dst`."""
+    frame becomes "each rank copies its own strips to their place" plus a completion flag per rank -- no rank relays
+    another rank's pixels (gather_image moves every strip twice and serialises on the destination).  Rank `dst`
+    creates the segment, the others attach after the barrier in open(); close() unlinks it on `dst`.
 
-    def __init__(self, name, W, H, dtype=np.float32):
-        self.name, self.W, self.H, self.dtype = name, W, H, np.dtype(dtype)
+    Behind the image the segment holds one int64 per rank: the number of frames whose strips that rank has delivered
+    (mark_done / wait_all: a frame is complete when every rank's counter has reached it; aligned 8-byte stores, one
+    writer per word).  register() page-locks the mapping (rm_host_register) so that rm_gather_strips can copy device
+    strips straight into it, asynchronously."""
+
+    def __init__(self, name, W, H, dtype=np.float32, slots=1):
+        self.name, self.W, self.H, self.dtype, self.slots = name, W, H, np.dtype(dtype), max(1, int(slots))
         self._shm = None
-        self.array = None
+        self.array = None       # slot 0; frames in flight use slot(k % slots), one image each
+        self.images = None      # (slots, H, W, 4)
+        self.flags = None
+        self._registered = False
 
     def open(self, rank, world, barrier, dst=0):
         from multiprocessing import shared_memory
-        nbytes = self.H * self.W * 4 * self.dtype.itemsize
+        nbytes = self.slots * self.H * self.W * 4 * self.dtype.itemsize
+        self._image_bytes = (nbytes + 4095) // 4096 * 4096
+        total = self._image_bytes + 8 * max(world, 1)
         if rank == dst:
-            self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=max(nbytes, 1))
+            self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=total)
+            np.ndarray((max(world, 1),), dtype=np.int64, buffer=self._shm.buf, offset=self._image_bytes)[:] = 0
         if world > 1:
             barrier()
         if rank != dst:
@@ -92,15 +103,58 @@ class SharedImage:
                 resource_tracker.unregister(self._shm._name, "shared_memory")
             except Exception:
                 pass
-        self.array = np.ndarray((self.H, self.W, 4), dtype=self.dtype, buffer=self._shm.buf)
+        self.images = np.ndarray((self.slots, self.H, self.W, 4), dtype=self.dtype, buffer=self._shm.buf)
+        self.array = self.images[0]
+        self.flags = np.ndarray((max(world, 1),), dtype=np.int64, buffer=self._shm.buf, offset=self._image_bytes)
         self._owner = rank == dst
+        self._world = max(world, 1)
         return self
+
+    @property
+    def address(self):
+        return self.images.ctypes.data
+
+    def slot(self, i):
+        return self.images[i % self.slots]
+
+    def slot_address(self, i):
+        return self.images.ctypes.data + (i % self.slots) * self.H * self.W * 4 * self.dtype.itemsize
+
+    def register(self):
+        """Page-lock the image for asynchronous device-to-host copies (needs the HIP library; GPU ranks only)."""
+        from . import _ffi
+        rc = _ffi.hip_lib().rm_host_register(self.address, self._image_bytes)
+        if rc != _ffi.RM_OK:
+            raise _ffi.RmError(rc, "rm_host_register of the shared frame failed")
+        self._registered = True
 
     def put_strips(self, compact, rank, world, strip_rows=DEFAULT_STRIP_ROWS):
         scatter_strips(self.array, compact, self.H, rank, world, strip_rows)
 
+    def mark_done(self, rank, frame_no):
+        """This rank's strips of frames < frame_no are in place."""
+        self.flags[rank] = frame_no
+
+    def wait_all(self, frame_no, timeout=60.0):
+        """Until every rank has delivered frame_no frames (the gather's only synchronisation)."""
+        import time
+        t0 = time.monotonic()
+        spins = 0
+        while int(self.flags.min()) < frame_no:
+            spins += 1
+            if spins > 200:
+                time.sleep(0)   # yield: ranks may outnumber cores
+            if time.monotonic() - t0 > timeout:
+                raise TimeoutError("a rank did not deliver frame %d within %.0f s" % (frame_no, timeout))
+
     def close(self, barrier=None):
+        if self._registered:
+            from . import _ffi
+            _ffi.hip_lib().rm_host_unregister(self.address)
+            self._registered = False
         self.array = None
+        self.images = None
+        self.flags = None
         if barrier is not None:
             barrier()
         if self._shm is not None:

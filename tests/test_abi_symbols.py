@@ -41,7 +41,7 @@ def test_struct_sizes_match_reference_blobs():
 
 def test_version_and_status_strings():
     L = _ffi.hip_lib()
-    assert L.rm_abi_version() == 1
+    assert L.rm_abi_version() == 2
     for s in range(0, -12, -1):
         assert L.rm_status_string(s) not in (None, b"", b"unknown status")
     assert L.rm_status_string(-99) == b"unknown status"

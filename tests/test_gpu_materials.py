@@ -113,11 +113,11 @@ def test_table_checks_and_untagged_programs(res, oracle):
     res.set_materials([(0.9, 0.9, 0.9)] * 4)
     res.set_program(cc8, w8)
     assert res.draw(W, H).tobytes() == oracle.render(u, lim, cc8, w8, W, H, threads=4).tobytes()
-    # the kernels of earlier generations render reference node types only
+    # the v1 kernel renders reference node types only
     res.set_program(cc, w)
     res.set_materials(scenes.MATERIAL_TABLE)
     res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
-    for k in (_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE):
+    for k in (_ffi.RM_KERNEL_PIXEL,):
         res.set_option(_ffi.RM_OPT_KERNEL, k)
         with pytest.raises(_ffi.RmError) as e:
             res.draw(W, H)

@@ -15,17 +15,13 @@ from ray_marching_amd import _ffi, camera, csg, renderer
 pytestmark = pytest.mark.gpu
 
 TOLERANCE = 1e-4      # contract (BASELINE.json north_star); asserted bit-exact below
-KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_RAYPOOL_LDS,
-           _ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_MULTI2_LDS,
-           _ffi.RM_KERNEL_MULTI4, _ffi.RM_KERNEL_MULTI4_LDS, _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS,
-           _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]
+KERNELS = [_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS]
 # pseudo variant: the default kernel with its structure-specialised (hipRTC) march kernel, compiled synchronously;
 # every explicitly named variant above runs with specialisation off, i.e. the interpreter kernels
 KERNEL_SPEC = 1000
 KERNEL_SPEC_PRUNE = 1001     # ... plus far-primitive pruning (RM_OPT_PRUNE = 1; opt-in)
 KERNELS += [KERNEL_SPEC, KERNEL_SPEC_PRUNE]
-KERNEL_IDS = ["pixel", "raypool", "raypool_lds", "multi1", "multi1_lds", "multi2", "multi2_lds", "multi4",
-              "multi4_lds", "queue", "queue_lds", "v5", "v5_lds", "v5_spec", "v5_spec_prune"]
+KERNEL_IDS = ["pixel", "v5", "v5_lds", "v5_spec", "v5_spec_prune"]
 IDX = G.index()
 
 
@@ -173,10 +169,8 @@ CULL_CAMERAS = {
 
 
 @pytest.mark.parametrize("cam", sorted(CULL_CAMERAS))
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_MULTI2,
-                                    _ffi.RM_KERNEL_QUEUE, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5,
-                                    _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE],
-                         ids=["multi1", "multi1_lds", "multi2", "queue", "queue_lds", "v5", "v5_lds", "v5_spec", "v5_spec_prune"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE],
+                         ids=["v5", "v5_lds", "v5_spec", "v5_spec_prune"])
 def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
     """The bounding-cone shortcut must never change a pixel: culling on == culling off == oracle,
     for cameras outside, inside, far from and grazing the scene, and for several min_dist."""
@@ -205,9 +199,8 @@ def test_miss_ray_culling_is_exact(res, oracle, cam, kernel):
             assert_same(bal, ref)
 
 
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC,
-                                    KERNEL_SPEC_PRUNE],
-                         ids=["multi1_lds", "queue_lds", "v5_lds", "v5_spec", "v5_spec_prune"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE],
+                         ids=["v5_lds", "v5_spec", "v5_spec_prune"])
 def test_culling_with_arbitrary_uniform_matrices(res, oracle, kernel):
     """The uniform block is three opaque blobs to the pipeline: the miss tests must hold for ANY matrices, not
     only the reference camera's.  wgsl:62 normalises a vec4, so whenever pt_world.w != ro.w the ray direction
@@ -288,9 +281,8 @@ def test_culling_degenerate_primitives_and_empty_scene(res, oracle):
         assert_same(res.draw(W, H), oracle.render(u, lim, 0, [], W, H, threads=4))
 
 
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL,
-                                    _ffi.RM_KERNEL_MULTI2, _ffi.RM_KERNEL_QUEUE_LDS, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
-                         ids=["default", "pixel", "raypool", "multi2", "queue_lds", "v5_lds", "v5_spec"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_DEFAULT, _ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC],
+                         ids=["default", "pixel", "v5_lds", "v5_spec"])
 def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     """rm_draw_strips: the multi-GPU tiling partition.  Every rank's strips, scattered back,
     must reproduce the single-GPU frame byte for byte (tiling invariance)."""
@@ -338,10 +330,14 @@ def test_extension_node_types_vs_oracle(res, oracle, name, kernel):
 def test_reference_only_kernels_reject_extension_programs(res, oracle):
     cc, w = oracle.serialize(*scenes.g8x())
     u, *_ = oracle.orbit_uniforms((16.0, 16.0))
-    for kernel in (_ffi.RM_KERNEL_PIXEL, _ffi.RM_KERNEL_RAYPOOL, _ffi.RM_KERNEL_MULTI1_LDS, _ffi.RM_KERNEL_QUEUE):
-        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=(0.01, 100.0, 16), kernel=kernel)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=(0.01, 100.0, 16), kernel=_ffi.RM_KERNEL_PIXEL)
+    with pytest.raises(_ffi.RmError) as e:
+        res.draw(16, 16)
+    assert e.value.status == _ffi.RM_ERR_ARG
+    # the v2-v4 variants of ABI version 1 (2..11) are retired: selecting one is an argument error, nothing is launched
+    for retired in range(2, 12):
         with pytest.raises(_ffi.RmError) as e:
-            res.draw(16, 16)
+            res.set_option(_ffi.RM_OPT_KERNEL, retired)
         assert e.value.status == _ffi.RM_ERR_ARG
     res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_DEFAULT)
 
@@ -587,8 +583,8 @@ def test_8bit_output_formats(res, oracle, fmt, bgra, kernel):
         for i, f in enumerate(frames):
             want = oracle.quantize_unorm8(oracle.render(f, (0.01, 100.0, 96), cc, w, W, H, threads=4), bgra=bgra)
             assert batch[i].tobytes() == want.tobytes()
-        # the older kernels do not have an output stage
-        res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_MULTI1_LDS)
+        # the v1 kernel does not have an output stage
+        res.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_PIXEL)
         with pytest.raises(_ffi.RmError) as e:
             res.draw(W, H)
         assert e.value.status == _ffi.RM_ERR_ARG
@@ -844,3 +840,168 @@ def test_8k_config_row_bands_vs_oracle(res, oracle):
     for r0, rows in [(1300, 2), (2161, 2), (3000, 1)]:
         assert_same(full[r0:r0 + rows], oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=16))
     del full
+
+
+def orbit_frame_uniforms(oracle, W, H, f, n_frames=1024):
+    """Uniforms of frame f of the orbit batch (BASELINE config 5): yaw 2 pi f / N, pitch -0.25, radius 5, through the
+    oracle's controller and prepare()."""
+    import math
+    L = oracle.lib()
+    orb = type(oracle.orbit_uniforms((1.0, 1.0))[3])()
+    t = np.zeros(3, np.float32)
+    f32p = C.POINTER(C.c_float)
+    L.rmo_orbit_new(C.byref(orb), t.ctypes.data_as(f32p), 5.0)
+    orb.yaw, orb.pitch, orb.radius = 2.0 * math.pi * f / n_frames, -0.25, 5.0
+    pos, q = np.zeros(3, np.float32), np.zeros(4, np.float32)
+    L.rmo_orbit_camera(C.byref(orb), pos.ctypes.data_as(f32p), q.ctypes.data_as(f32p))
+    u = type(oracle.orbit_uniforms((1.0, 1.0))[0])()
+    assert L.rmo_prepare_uniforms(float(W), float(H), pos.ctypes.data_as(f32p), q.ctypes.data_as(f32p), C.byref(u)) == 0
+    return u
+
+
+def test_library_defaults_full_frame_vs_oracle(oracle):
+    """The metric frame exactly as bench.py draws it: a FRESH context, no rm_set_option call at all (so whatever the
+    library's defaults are -- pruned + grouped far tests + four taps in one pass + temporal tile order, compiled in the
+    background) against the oracle, every pixel; drawn until the specialised kernel has taken over, and once more so
+    that the tile order comes from the previous frame's measurements."""
+    import time
+    W, H = 1920, 1080
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    lim = (0.01, 100.0, 256)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=16)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        r.set_program(cc, w)
+        assert_same(r.draw(W, H), ref)                      # interpreter kernel while the compiler runs
+        t0 = time.monotonic()
+        while r.info(_ffi.RM_INFO_JIT_STATE) == 1.0 and time.monotonic() - t0 < 120:
+            time.sleep(0.05)
+        assert r.info(_ffi.RM_INFO_JIT_STATE) == 2.0, r.jit_log()
+        for _ in range(2):
+            assert_same(r.draw(W, H), ref)
+            assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 1
+    finally:
+        r.close()
+
+
+@pytest.mark.parametrize("scene", ["g32", "g32s"])
+def test_4k_configs_row_bands_vs_oracle(oracle, scene):
+    """BASELINE configs[2] (3840x2160, 32-node graph with smooth-min blends, 256 steps) and configs[4] (the orbit batch
+    at 3840x2160, G32) at their full size on the default path: two orbit-batch cameras each, sampled row bands bit-exact
+    against the oracle, alpha plane and finiteness of the whole frame."""
+    W, H = 3840, 2160
+    lim = (0.01, 100.0, 256)
+    cc, w = oracle.serialize(*scenes.SCENES[scene]())
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_limits(lim)
+        r.set_program(cc, w)
+        for f in (0, 341):                                   # frame 0 and one a third of the way round
+            u = orbit_frame_uniforms(oracle, W, H, f)
+            r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+            full = r.draw(W, H)
+            assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1
+            assert np.isfinite(full).all() and np.array_equal(full[..., 3], np.ones((H, W), np.float32))
+            for r0, rows in [(700, 2), (1081, 3), (1500, 2)]:
+                assert_same(full[r0:r0 + rows], oracle.render(u, lim, cc, w, W, H, row0=r0, rows=rows, threads=16))
+            del full
+    finally:
+        r.close()
+
+
+def test_host_draw_is_ordered_with_draws_on_a_caller_stream(oracle):
+    """Draws of one context share its scratch buffers (program copy, work list, counters).  A host-destination draw runs
+    on the context's own stream: it must wait for device-destination draws the caller queued on ANOTHER stream, and a
+    later draw on that stream must wait for it (rm_abi.h, order_with_previous)."""
+    torch = pytest.importorskip("torch")
+    W, H = 480, 270
+    lim = (0.01, 100.0, 256)
+    cc32, w32, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    cc8, w8 = oracle.serialize(*scenes.g8())
+    uu = _ffi.Uniforms.from_buffer_copy(bytes(u))
+    ref32 = oracle.render(u, lim, cc32, w32, W, H, threads=8)
+    ref8 = oracle.render(u, lim, cc8, w8, W, H, threads=8)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
+        r.set_limits(lim)
+        r.set_uniforms(uu)
+        s = torch.cuda.Stream()
+        outs = [torch.zeros((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(6)]
+        for rep in range(3):
+            r.set_program(cc32, w32)
+            for o in outs[:3]:                               # three frames queued on the caller's stream
+                r.draw_device(W, H, o.data_ptr(), stream=s.cuda_stream)
+            r.set_program(cc8, w8)                           # program change + host draw while they are in flight
+            host = r.draw(W, H)
+            r.set_program(cc32, w32)
+            for o in outs[3:]:
+                r.draw_device(W, H, o.data_ptr(), stream=s.cuda_stream)
+            s.synchronize()
+            assert_same(host, ref8)
+            for o in outs:
+                assert_same(o.cpu().numpy(), ref32)
+                o.zero_()
+    finally:
+        r.close()
+
+
+def test_64k_command_buffer_falls_back_to_the_scalar_cache_variant(res, oracle):
+    """rm_resize_command_buffer admits 64 KB of commands; such a program's records do not fit a workgroup's LDS next to
+    the ray buffers, so the draw reads it through the scalar cache instead of failing."""
+    rng = np.random.default_rng(5)
+    t = scenes._Tab()
+    n = 2700                                              # 2700 spheres + 2699 unions = 16 199 words < 16 383
+    prims = [t.sphere((float(rng.uniform(-3, 3)), float(rng.uniform(-1, 1.5)), float(rng.uniform(-3, 3))), float(rng.uniform(0.02, 0.08)))
+             for _ in range(n)]
+    cc, w = oracle.serialize(t.nodes, scenes._fold_left(t, prims))
+    assert 4 * (len(w) + 1) <= 65536 and len(w) > 16000
+    W, H = 48, 32
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    lim = (0.01, 100.0, 64)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.resize_command_buffer(65536)
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        r.set_program(cc, w)
+        assert_same(r.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=16))
+    finally:
+        r.close()
+
+
+def test_gather_strips_reassembles_the_frame_on_the_host(oracle):
+    """rm_gather_strips: every rank's strips, copied from its compact device buffer to their rows of ONE host frame
+    (here: all 'ranks' in one process, pinned and pageable destinations), give the single-GPU frame byte for byte."""
+    torch = pytest.importorskip("torch")
+    from ray_marching_amd import shard
+    W, H = 200, 104                                       # 6.5 strips of 16 rows
+    lim = (0.01, 100.0, 96)
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=8)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        r.set_program(cc, w)
+        s = torch.cuda.Stream()
+        for world in (1, 2, 3, 8):
+            pinned = torch.zeros((H, W, 4), dtype=torch.float32).pin_memory()
+            pageable = np.zeros((H, W, 4), np.float32)
+            for rank in range(world):
+                rows = shard.strip_row_count(H, 16, rank, world)
+                buf = torch.zeros((max(rows, 1), W, 4), dtype=torch.float32, device="cuda")
+                assert r.draw_strips_device(W, H, 16, rank, world, buf.data_ptr(), stream=s.cuda_stream) == rows
+                r.gather_strips(W, H, 16, rank, world, buf.data_ptr(), pinned.data_ptr(), stream=s.cuda_stream)
+                r.gather_strips(W, H, 16, rank, world, buf.data_ptr(), pageable.ctypes.data, stream=s.cuda_stream)
+                s.synchronize()
+            assert_same(pinned.numpy(), ref)
+            assert_same(pageable, ref)
+        with pytest.raises(_ffi.RmError):
+            r.gather_strips(W, H, 8, 0, 1, 1, 1)          # strip_rows must be a multiple of 16
+    finally:
+        r.close()

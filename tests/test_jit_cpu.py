@@ -212,9 +212,18 @@ def test_disk_cache_of_compiled_kernels(oracle, tmp_path):
     second = run("g8")
     assert second == ["0", first[1], "loaded"]
     assert run("g32")[2] == "compiled" and len(list(tmp_path.iterdir())) == 2
-    (tmp_path / files[0]).write_bytes(b"not a code object")
-    assert run("g8")[2] == "compiled"                      # a damaged entry is ignored and replaced
-    assert (tmp_path / files[0]).read_bytes()[:4] == b"\x7fELF"
+    good = (tmp_path / files[0]).read_bytes()
+    assert good[:8] == b"RMJITCO\x01" and good[32:36] == b"\x7fELF"      # 32-byte header (length, checksum), then the code object
+    assert int.from_bytes(good[8:16], "little") == len(good) - 32
+    # a damaged entry -- garbage, a truncated file, one flipped payload bit (only the checksum can see that one) -- is
+    # recognised when it is READ, dropped and replaced; a later process loads the rewritten file
+    flipped = bytearray(good)
+    flipped[len(good) // 2] ^= 0x10
+    for damaged in (b"not a code object", good[:len(good) // 2], bytes(flipped), good + b"tail"):
+        (tmp_path / files[0]).write_bytes(damaged)
+        assert run("g8")[2] == "compiled"
+        assert (tmp_path / files[0]).read_bytes() == good
+        assert run("g8")[2] == "loaded"
 
 
 def test_four_taps_in_one_pass_function(oracle):

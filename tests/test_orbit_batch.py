@@ -49,6 +49,36 @@ def _args(out_dir, **kw):
     return argparse.Namespace(**d)
 
 
+def _expected_frame(oracle, a, cc, w, f):
+    """Frame f of the batch through the oracle: its controller at yaw 2 pi f / N, pitch -0.25, r 5, its prepare()."""
+    import ctypes as C
+    L = oracle.lib()
+    orb = type(oracle.orbit_uniforms((1.0, 1.0))[3])()
+    t = np.zeros(3, np.float32)
+    L.rmo_orbit_new(C.byref(orb), t.ctypes.data_as(C.POINTER(C.c_float)), 5.0)
+    orb.yaw, orb.pitch, orb.radius = orbit_batch.orbit_yaw(f, a.frames), -0.25, 5.0
+    pos, q = np.zeros(3, np.float32), np.zeros(4, np.float32)
+    L.rmo_orbit_camera(C.byref(orb), pos.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(C.POINTER(C.c_float)))
+    u = type(oracle.orbit_uniforms((1.0, 1.0))[0])()
+    assert L.rmo_prepare_uniforms(float(a.width), float(a.height), pos.ctypes.data_as(C.POINTER(C.c_float)),
+                                  q.ctypes.data_as(C.POINTER(C.c_float)), C.byref(u)) == 0
+    return oracle.render(u, (0.01, 100.0, a.max_iter), cc, w, a.width, a.height, threads=8)
+
+
+@pytest.mark.gpu
+def test_orbit_batch_with_the_32_node_graph(tmp_path, oracle):
+    """BASELINE config 5's scene (G32, 256 steps) through the batch driver, reduced size: every frame's PPM file equals
+    quantise(oracle frame); three ranks cover the batch without overlap."""
+    a = _args(tmp_path, scene="g32", frames=9, width=192, height=108, max_iter=256)
+    cc, w = oracle.serialize(*scenes.g32())
+    done = [orbit_batch.render_batch(a, rank=r, world=3, device=0) for r in range(3)]
+    assert [d["frames_rendered"] for d in done] == [3, 3, 3]
+    for f in range(a.frames):
+        data = open(orbit_batch.frame_path(a.out_dir, f, "ppm"), "rb").read()
+        body = data[len(orbit_batch.ppm_header(a.width, a.height)):]
+        assert body == oracle.quantize_unorm8(_expected_frame(oracle, a, cc, w, f))[..., :3].tobytes(), f
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", ["ppm", "f32"])
 def test_orbit_batch_matches_the_oracle_and_resumes(tmp_path, oracle, fmt):
@@ -56,21 +86,8 @@ def test_orbit_batch_matches_the_oracle_and_resumes(tmp_path, oracle, fmt):
     s = orbit_batch.render_batch(a, rank=0, world=1, device=0)
     assert s["frames_rendered"] == 6 and s["frames_skipped"] == 0
     cc, w = oracle.serialize(*scenes.g8())
-    lim = (0.01, 100.0, a.max_iter)
-
     def expect(f):
-        L = oracle.lib()
-        import ctypes as C
-        orb = type(oracle.orbit_uniforms((1.0, 1.0))[3])()
-        t = np.zeros(3, np.float32)
-        L.rmo_orbit_new(C.byref(orb), t.ctypes.data_as(C.POINTER(C.c_float)), 5.0)
-        orb.yaw, orb.pitch, orb.radius = orbit_batch.orbit_yaw(f, a.frames), -0.25, 5.0
-        pos, q = np.zeros(3, np.float32), np.zeros(4, np.float32)
-        L.rmo_orbit_camera(C.byref(orb), pos.ctypes.data_as(C.POINTER(C.c_float)), q.ctypes.data_as(C.POINTER(C.c_float)))
-        u = type(oracle.orbit_uniforms((1.0, 1.0))[0])()
-        assert L.rmo_prepare_uniforms(float(a.width), float(a.height), pos.ctypes.data_as(C.POINTER(C.c_float)),
-                                      q.ctypes.data_as(C.POINTER(C.c_float)), C.byref(u)) == 0
-        return oracle.render(u, lim, cc, w, a.width, a.height, threads=4)
+        return _expected_frame(oracle, a, cc, w, f)
 
     for f in range(a.frames):
         data = open(orbit_batch.frame_path(a.out_dir, f, fmt), "rb").read()

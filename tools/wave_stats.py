@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ray_marching_amd import _ffi, camera, csg, renderer  # noqa: E402
 
 p = argparse.ArgumentParser()
-p.add_argument("--kernel", type=int, default=5)
+p.add_argument("--kernel", type=int, default=13)
 p.add_argument("--width", type=int, default=1920)
 p.add_argument("--height", type=int, default=1080)
 p.add_argument("--scene", default="g32")
