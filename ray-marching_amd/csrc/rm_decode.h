@@ -36,7 +36,7 @@ struct RmDecoded {
     // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
     // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
     // on the structure only -- the generated code is compiled per structure -- the spheres on the parameters:
-    // p[0..2] centre, p[3] radius R', p[4] = R' * 1.000005 rounded up (what spec_sphere_far reads), where
+    // p[0..2] centre, p[3] = p[4] = R' * 1.000005 rounded up (what spec_group_near reads), where
     //   R' = (R + 2e-6 (|c|_1 + R)) (1 + 1e-6),  R = max_i (|c_i - c| + rho_i)   (rho: radius / half-diagonal)
     // covers a member's own evaluation error: a member's value at p is >= |p - c| - R in real arithmetic (triangle
     // inequality; a box's distance is at least the distance to its bounding sphere), and its computed value differs
@@ -276,8 +276,9 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             g.op = RM_OP(RM_KIND_SPHERE, RM_MODE_PUSH, 0);
             // the centre is rounded to binary32: its displacement (<= an ulp of |c|) is inside the 2e-6 |c|_1 slack
             g.p[0] = (float)c[0]; g.p[1] = (float)c[1]; g.p[2] = (float)c[2];
-            g.p[3] = std::nextafterf((float)R, INFINITY);
-            g.p[4] = std::nextafterf((float)((double)g.p[3] * 1.000005), INFINITY);
+            // p[3] = p[4] = R' * 1.000005 rounded up: the one radius the test reads, next to the centre (one 16-byte read)
+            g.p[4] = std::nextafterf((float)((double)std::nextafterf((float)R, INFINITY) * 1.000005), INFINITY);
+            g.p[3] = g.p[4];
             d.groups.push_back(g);
             first = nullptr;
         }

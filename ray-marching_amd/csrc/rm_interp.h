@@ -42,6 +42,11 @@ RM_DEV float vmax_negb(float a, float b) {  // max(a, -b)
 struct SqrtGuard {
     uint32_t lo = 0xFFFFFFFFu, hi = 0u;  // min / max over the (biased) bit patterns of all sqrt arguments
     RM_DEV bool bad() const { return lo < kLoBits || hi > 0x7F7FFFFFu; }
+    // any lane of the wave: two compares whose wave masks are combined on the scalar side (a ballot of the OR would go
+    // through a VGPR and back, see spec_any_near in rm_kernel_v5.h)
+    RM_DEV bool any_bad() const {
+        return (__builtin_amdgcn_ballot_w64(lo < kLoBits) | __builtin_amdgcn_ballot_w64(hi > 0x7F7FFFFFu)) != 0ull;
+    }
     static constexpr uint32_t kLoBits = 0x0F800000u - 1u;  // bits(2^-96) - 1
 };
 RM_DEV float vmax(float a, float b) {  // direct v_max_f32, see vmin

@@ -128,7 +128,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     char line[512];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
+    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
     if (prune) {
         s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test
@@ -151,13 +151,13 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     pos.push_back(0);
     // all group tests up front: their LDS reads go out together instead of one stalling in front of every pair
     for (int g = 0; 2 * g + 1 < n_pruned_total; g++) {
-        const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u + 1u;
-        std::snprintf(line, sizeof line, "    const bool g%d = spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, x0, y0, z0), thrk));\n", g, goff, goff);
+        const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u;
+        std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, x0, y0, z0, thrk);\n", g, goff);
         s += line;
     }
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u + 1u;  // first parameter of record i, in dwords
+        const unsigned off = (unsigned)i * 8u;  // first parameter of record i, in dwords (records are staged rotated: lds_load4)
         if (kind == RM_KIND_XFORM) {  // space transformation: a new position value (push) or back to the enclosing one (pop)
             const int c = pos.back();
             if ((mode & 1u) == 0u) {
@@ -266,7 +266,7 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
     char line[768];
     s += "namespace rmk {\n";
     s += "template <bool FAST>\n";
-    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, bool live, SqrtGuard& tiny, float (&f)[4]) {\n";
+    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]) {\n";
     if (prune) {
         s += "    const float thrk = thr * 1.000005f;\n";
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";
@@ -280,8 +280,8 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
         int total = 0;
         for (const RmRecord& r : rec) total += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
         for (int g = 0; 2 * g + 1 < total; g++) {
-            const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u + 1u;
-            std::snprintf(line, sizeof line, "    const bool g%d = spec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk));\n", g, goff, goff);
+            const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u;
+            std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, cx, cy, cz, thrk);\n", g, goff);
             s += line;
         }
     }
@@ -294,7 +294,7 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
     pos.push_back(0);
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u + 1u;
+        const unsigned off = (unsigned)i * 8u;
         if (kind == RM_KIND_XFORM) {
             if (prune) return false;  // pruned programs have no transforms
             const int c = pos.back();

@@ -48,12 +48,13 @@ RM_DEV LdsF lds_vector_base(const void* generic_lds_ptr) {
     asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
     return (LdsF)(__SIZE_TYPE__)v;  // LDS pointers are 32 bits wide; the widening only silences the host pass
 }
+// `live`: wave mask of the lanes whose value will be used (far tests ignore the others)
 template <bool FAST>
-RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, bool live, SqrtGuard& tiny, uint32_t& n_eval);
+RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval);
 #ifdef RM_JIT_TAPS4
 // The four normal taps of a hit at c in one pass (rm_jit.h generate_map_scene_taps): f[t] = map_scene(c + k_t eps).
 template <bool FAST>
-RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, bool live, SqrtGuard& tiny, float (&f)[4]);
+RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]);
 #endif
 
 // ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
@@ -81,9 +82,26 @@ RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, boo
 // NaN or inf anywhere (parameters, position, thr) makes the comparison false: the primitive is evaluated.
 // Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned.
 constexpr float kPruneAbs = 4.0e-6f;
-RM_DEV bool spec_any_near(bool live, bool far) { return __ballot(live && !far) != 0ull; }
+// "is the leaf near for ANY live lane": the wave mask of the comparison itself (one v_cmp writing a scalar pair),
+// combined with the live mask on the scalar side.  Written as __ballot(live && !far) the predicate is not a comparison
+// any more and the compiler materialises it in a VGPR and compares it back (v_cndmask + v_cmp_ne: two vector
+// instructions per far test, ~9 % of the march kernel's).
+RM_DEV bool spec_any_near(unsigned long long live, bool far) { return (__builtin_amdgcn_ballot_w64(!far) & live) != 0ull; }
+
+// Parameter reads of the generated code.  A specialised kernel stages every record ROTATED by one dword -- p[0..6] at
+// dwords 0..6, the opcode (which generated code never reads) at dword 7 -- so that the parameters of a record start on
+// a 32-byte boundary and are fetched with ONE ds_read_b128 (+ a ds_read_b64 for a box) instead of two or three
+// ds_read2_b32: the LDS pipe of a CU serves a wave64 b32 / b64 read in 2 cycles and a read2_b32 / b128 in 4
+// (MI355X_MICROARCH.md, LDS), it is shared by the four SIMDs, and at ~40 parameter reads per evaluation it was ~60 %
+// busy (SQ_ACTIVE_INST_LDS) next to a vector unit at ~80 %.
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
+typedef float lds_f2 __attribute__((ext_vector_type(2)));
+RM_DEV lds_f4 lds_load4(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f4*>(r); }
+RM_DEV lds_f2 lds_load2(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f2*>(r); }
+
 RM_DEV float spec_sphere_a(LdsF r, float qx, float qy, float qz) {
-    const float dx = qx - r[0], dy = qy - r[1], dz = qz - r[2];
+    const lds_f4 p = lds_load4(r);  // cx cy cz r
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     return (dx * dx + dy * dy) + dz * dz;  // the argument of sdf_sphere_t's sqrt, same operations
 }
 RM_DEV bool spec_sphere_far(LdsF r, float a, float thrk) {
@@ -92,12 +110,24 @@ RM_DEV bool spec_sphere_far(LdsF r, float a, float thrk) {
 }
 template <bool FAST>
 RM_DEV float spec_sphere_v(LdsF r, float a, SqrtGuard& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
+// Grouped far test (RmDecoded::groups): centre and pre-multiplied radius of the pair's bounding sphere in one 16-byte
+// read.  The squared distance is a bound here, not a value of the arithmetic contract, so it may use fused multiply-adds
+// (their rounding error is no larger than the unfused form's, which the factor 1.000005 in the radius covers).
+RM_DEV bool spec_group_near(unsigned long long live, LdsF r, float qx, float qy, float qz, float thrk) {
+    const lds_f4 p = lds_load4(r);  // cx cy cz R' * 1.000005
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float t = thrk + p.w;
+    return spec_any_near(live, a > t * t);
+}
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
+    const lds_f4 c = lds_load4(r);       // cx cy cz rx
+    const lds_f2 h = lds_load2(r + 4);   // ry rz
     SpecBox b;
-    b.qx = __builtin_fabsf(px - r[0]) - r[3];
-    b.qy = __builtin_fabsf(py - r[1]) - r[4];
-    b.qz = __builtin_fabsf(pz - r[2]) - r[5];
+    b.qx = __builtin_fabsf(px - c.x) - c.w;
+    b.qy = __builtin_fabsf(py - c.y) - h.x;
+    b.qz = __builtin_fabsf(pz - c.z) - h.y;
     const float mx = fmax_(b.qx, 0.0f), my = fmax_(b.qy, 0.0f), mz = fmax_(b.qz, 0.0f);
     b.a = (mx * mx + my * my) + mz * mz;  // as sdf_box_t
     return b;
@@ -110,23 +140,28 @@ RM_DEV float spec_box_v(const SpecBox& b, SqrtGuard& tiny) {
 // record's parameters in LDS (wave-uniform address, constant offset: a broadcast read).
 template <bool FAST>
 RM_DEV float spec_sphere(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
-    const float p[7] = {r[0], r[1], r[2], r[3], 0.0f, 0.0f, 0.0f};
+    const lds_f4 c = lds_load4(r);
+    const float p[7] = {c.x, c.y, c.z, c.w, 0.0f, 0.0f, 0.0f};
     return sdf_sphere_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
 RM_DEV float spec_box(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
-    const float p[7] = {r[0], r[1], r[2], r[3], r[4], r[5], 0.0f};
+    const lds_f4 c = lds_load4(r);
+    const lds_f2 h = lds_load2(r + 4);
+    const float p[7] = {c.x, c.y, c.z, c.w, h.x, h.y, 0.0f};
     return sdf_box_t<FAST>(qx, qy, qz, p, tiny);
 }
 template <bool FAST>
 RM_DEV float spec_cylinder(LdsF r, float qx, float qy, float qz, SqrtGuard& tiny) {
-    const float p[7] = {r[0], r[1], r[2], r[3], r[4], 0.0f, 0.0f};
+    const lds_f4 c = lds_load4(r);
+    const float p[7] = {c.x, c.y, c.z, c.w, r[4], 0.0f, 0.0f};
     return sdf_cylinder_t<FAST>(qx, qy, qz, p, tiny);
 }
 RM_DEV float spec_plane(LdsF r, float qx, float qy, float qz) {
-    return ((qx * r[0] + qy * r[1]) + qz * r[2]) + r[3];  // as exec_command
+    const lds_f4 n = lds_load4(r);
+    return ((qx * n.x + qy * n.y) + qz * n.z) + n.w;  // as exec_command
 }
-RM_DEV float spec_smooth_union(LdsF r, float a, float b, bool live) {  // as exec_command, RM_MODE_SMOOTH
+RM_DEV float spec_smooth_union(LdsF r, float a, float b, unsigned long long live) {  // as exec_command, RM_MODE_SMOOTH
     const float kk = r[0];
     float v = fmin_(a, b);
     if (kk > 0.0f) {
@@ -135,7 +170,7 @@ RM_DEV float spec_smooth_union(LdsF r, float a, float b, bool live) {  // as exe
         // that holds for every live lane of the wave -- most evaluations: two operands are within k of each other
         // only near the seams -- the division and the five operations after it are skipped (dead lanes' values are
         // never used).
-        if (kk < __uint_as_float(0x7F800000u) && __ballot(live && t > 0.0f) == 0ull) return v;
+        if (kk < __uint_as_float(0x7F800000u) && (__builtin_amdgcn_ballot_w64(t > 0.0f) & live) == 0ull) return v;
         const float h = fmax_(t, 0.0f) / kk;
         v = v - ((h * h) * kk) * 0.25f;
     }
@@ -325,7 +360,8 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float eps = 0.0001f;                                    // wgsl:136
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
-        for (uint32_t k = tid; k < (L.n_rec + L.n_grp) * 8u; k += 64u * WPT) lprog[k] = src[k];  // program, then group records
+        // program, then group records; generated code reads them rotated by one dword (parameters first: lds_load4)
+        for (uint32_t k = tid; k < (L.n_rec + L.n_grp) * 8u; k += 64u * WPT) lprog[SPEC ? ((k & ~7u) | ((k + 7u) & 7u)) : k] = src[k];
     }
     if (tid == 0u) *s_veto = 0u;
     __syncthreads();
@@ -339,18 +375,18 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const LdsF lprog_v = lds_vector_base(lprog);  // SPEC: the program's LDS copy, base address in a VGPR (see LdsF)
     uint32_t n_eval = 0u;  // diagnostics (pruned kernels compiled with statistics): leaves actually evaluated, per wave
     // map_scene (wgsl:187-203) at one point per lane
-    auto eval_scene = [&](float x, float y, float z, float thr, bool is_live) -> float {
+    auto eval_scene = [&](float x, float y, float z, float thr, unsigned long long live_mask) -> float {
         float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
         SqrtGuard tiny;
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
-            v[0] = map_scene_spec<true>(lprog_v, x, y, z, thr, is_live, tiny, n_eval);
-            if (__ballot(tiny.bad()) != 0ull) {
+            v[0] = map_scene_spec<true>(lprog_v, x, y, z, thr, live_mask, tiny, n_eval);
+            if (tiny.any_bad()) {
                 uint32_t again = 0u;
-                v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, is_live, tiny, again);
+                v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, live_mask, tiny, again);
             }
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
-            if (__ballot(tiny.bad()) != 0ull)  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
+            if (tiny.any_bad())  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
                 map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
         }
         return v[0];
@@ -505,10 +541,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             const float thr_c = __uint_as_float(hq_rid[e] & ~1023u) * 1.00001f + 3.5e-4f + (m + m);
             float f[4];
             SqrtGuard tiny;
-            map_scene_taps<true>(lprog_v, cx, cy, cz, thr_c, live4, tiny, f);
-            if (__ballot(tiny.bad()) != 0ull) map_scene_taps<false>(lprog_v, cx, cy, cz, thr_c, live4, tiny, f);
+            const unsigned long long live4_m = __builtin_amdgcn_ballot_w64(live4);
+            map_scene_taps<true>(lprog_v, cx, cy, cz, thr_c, live4_m, tiny, f);
+            if (tiny.any_bad()) map_scene_taps<false>(lprog_v, cx, cy, cz, thr_c, live4_m, tiny, f);
             n_iter++;
-            n_live += (uint32_t)__popcll(__ballot(live4));
+            n_live += (uint32_t)__popcll(live4_m);
             // n = ((k0 f0 + k1 f1) + k2 f2) + k3 f3, k = (+,-,-), (-,-,+), (-,+,-), (+,+,+); products with +-1 are exact
             const float nx = ((f[0] + -f[1]) + -f[2]) + f[3];
             const float ny = ((-f[0] + -f[1]) + f[2]) + f[3];
@@ -545,7 +582,8 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             if constexpr (SPEC) thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
         }
         n_iter++;
-        n_live += (uint32_t)__popcll(__ballot(is_live));
+        const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
+        n_live += (uint32_t)__popcll(live_m);
 #ifdef RM_PRIO_LONG_RAYS
         // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
         // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
@@ -556,7 +594,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             else __builtin_amdgcn_s_setprio(0);
         }
 #endif
-        const float sd = eval_scene(ex, ey, ez, thr, is_live);
+        const float sd = eval_scene(ex, ey, ez, thr, live_m);
 
         if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
             const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
@@ -578,7 +616,6 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
         // Written on wave masks (64-bit scalars) with explicit selects: left to itself the compiler turned the lane
         // predicates into 0/1 integers and back (17 vector instructions for what takes 7).
-        const unsigned long long live_m = __ballot(is_live);
         const unsigned long long hit_mask = live_m & __ballot(sd < L.min_dist);                       // wgsl:97
         const unsigned long long on_m = live_m & ~hit_mask;                                           // (a NaN is not a hit)
         const unsigned long long esc_m = on_m & __ballot(sd > L.max_dist);                            // wgsl:109-111

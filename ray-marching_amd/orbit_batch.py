@@ -1,5 +1,5 @@
 """Offline camera-orbit batch (BASELINE config 5): N frames of one scene, frame f at
-yaw = 2*pi*f/N, sharded over the ranks of one node (frame f -> rank f % world, no collective), written as binary PPM.
+yaw = 2*pi*f/N, sharded over the ranks of one node (frame f -> rank f % world, no collective), written as binary PPM or PNG.
 
   output stage   frames are rendered in an 8-bit format (4 B/pixel on the device and over PCIe, a quarter of RGBA32F);
                  the RGBA32F path stays available (--format f32 writes raw little-endian float32 RGBA, .rgba32f)
@@ -19,16 +19,23 @@ import json
 import math
 import os
 import queue
+import struct
 import threading
 import time
+import zlib
 
 import numpy as np
 
 from . import shard
 
 
+EXT = {"ppm": "ppm", "png": "png", "f32": "rgba32f"}
+PNG_SIGNATURE = b"\x89PNG\r\n\x1a\n"
+PNG_IEND = struct.pack(">I", 0) + b"IEND" + struct.pack(">I", zlib.crc32(b"IEND"))
+
+
 def frame_path(out_dir, f, fmt):
-    return os.path.join(out_dir, "frame_%05d.%s" % (f, "ppm" if fmt != "f32" else "rgba32f"))
+    return os.path.join(out_dir, "frame_%05d.%s" % (f, EXT[fmt]))
 
 
 def ppm_header(W, H):
@@ -36,22 +43,54 @@ def ppm_header(W, H):
 
 
 def expected_size(W, H, fmt):
+    """Exact file size of a finished frame; None for PNG (compressed: see png_is_complete)."""
+    if fmt == "png":
+        return None
     return len(ppm_header(W, H)) + W * H * 3 if fmt != "f32" else W * H * 16
+
+
+def png_chunk(kind, data):
+    return struct.pack(">I", len(data)) + kind + data + struct.pack(">I", zlib.crc32(kind + data))
+
+
+def png_bytes(img, level=1):
+    """8-bit RGB PNG (colour type 2, no interlace, filter 0 on every row) of an (H, W, >=3) uint8 array, standard library
+    only.  level 1: the batch is bound by the file system, not by the size of the files."""
+    H, W = img.shape[:2]
+    rows = np.empty((H, 1 + 3 * W), dtype=np.uint8)
+    rows[:, 0] = 0
+    rows[:, 1:] = np.ascontiguousarray(img[..., :3]).reshape(H, 3 * W)
+    ihdr = struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)
+    return PNG_SIGNATURE + png_chunk(b"IHDR", ihdr) + png_chunk(b"IDAT", zlib.compress(memoryview(rows).cast("B"), level)) + PNG_IEND
+
+
+def png_is_complete(path, W, H):
+    """A finished PNG of the expected size: signature, an IHDR with these dimensions, the IEND trailer at the very end
+    (files are renamed into place only when complete, so this is a consistency check, not a parse)."""
+    try:
+        with open(path, "rb") as fh:
+            head = fh.read(33)
+            fh.seek(-12, os.SEEK_END)
+            tail = fh.read(12)
+    except OSError:
+        return False
+    return (len(head) == 33 and head[:8] == PNG_SIGNATURE and head[12:16] == b"IHDR"
+            and struct.unpack(">II", head[16:24]) == (W, H) and tail == PNG_IEND)
+
+
+def frame_is_done(out_dir, f, W, H, fmt):
+    p = frame_path(out_dir, f, fmt)
+    if fmt == "png":
+        return png_is_complete(p, W, H)
+    try:
+        return os.path.getsize(p) == expected_size(W, H, fmt)
+    except OSError:
+        return False
 
 
 def frames_todo(out_dir, n_frames, rank, world, W, H, fmt):
     """This rank's frames that still have to be rendered (resume by frame index)."""
-    want = expected_size(W, H, fmt)
-    todo = []
-    for f in shard.frames_of_rank(n_frames, rank, world):
-        p = frame_path(out_dir, f, fmt)
-        try:
-            if os.path.getsize(p) == want:
-                continue
-        except OSError:
-            pass
-        todo.append(f)
-    return todo
+    return [f for f in shard.frames_of_rank(n_frames, rank, world) if not frame_is_done(out_dir, f, W, H, fmt)]
 
 
 def write_frame(out_dir, f, img, fmt):
@@ -61,6 +100,8 @@ def write_frame(out_dir, f, img, fmt):
     with open(tmp, "wb") as fh:
         if fmt == "f32":
             fh.write(memoryview(np.ascontiguousarray(img, dtype=np.float32)).cast("B"))
+        elif fmt == "png":
+            fh.write(png_bytes(img))
         else:
             H, W = img.shape[:2]
             fh.write(ppm_header(W, H))
@@ -191,7 +232,8 @@ def parse(argv=None):
     p.add_argument("--height", type=int, default=2160)
     p.add_argument("--scene", default="g32")
     p.add_argument("--max-iter", type=int, default=256)
-    p.add_argument("--format", choices=["ppm", "f32"], default="ppm", help="ppm: 8-bit output stage; f32: raw RGBA32F")
+    p.add_argument("--format", choices=["ppm", "png", "f32"], default="ppm",
+                   help="ppm / png: 8-bit output stage (png: zlib level 1, standard library only); f32: raw RGBA32F")
     p.add_argument("--slots", type=int, default=4, help="device / pinned-host buffer pairs in flight")
     p.add_argument("--writers", type=int, default=3, help="file-writer threads")
     p.add_argument("--all-ranks-on-device0", action="store_true", help="rehearsal on a one-GPU box: every rank renders on GPU 0")

@@ -893,7 +893,7 @@ def test_4k_configs_row_bands_vs_oracle(oracle, scene):
     against the oracle, alpha plane and finiteness of the whole frame."""
     W, H = 3840, 2160
     lim = (0.01, 100.0, 256)
-    cc, w = oracle.serialize(*scenes.SCENES[scene]())
+    cc, w = oracle.serialize(*{**scenes.SCENES, **scenes.EXT_SCENES}[scene]())
     r = renderer.RayMarchingResources(0)
     try:
         r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)

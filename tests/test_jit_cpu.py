@@ -27,10 +27,10 @@ def test_generated_code_follows_the_postfix_program(oracle):
     plain = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w))]
     assert plain == [
         "const float x0 = qx, y0 = qy, z0 = qz;",
-        "const float v0 = spec_sphere<FAST>(lp + 1, x0, y0, z0, tiny);",
-        "const float v1 = vmin(v0, spec_box<FAST>(lp + 9, x0, y0, z0, tiny));",
-        "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 17, x0, y0, z0, tiny));",
-        "const float v3 = vmin(v2, spec_box<FAST>(lp + 25, x0, y0, z0, tiny));",
+        "const float v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);",
+        "const float v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
+        "const float v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 16, x0, y0, z0, tiny));",
+        "const float v3 = vmin(v2, spec_box<FAST>(lp + 24, x0, y0, z0, tiny));",
         "__builtin_amdgcn_sched_barrier(0);",
         "return v3;",
     ]
@@ -39,23 +39,24 @@ def test_generated_code_follows_the_postfix_program(oracle):
                         "const float inf = __uint_as_float(0x7F800000u);", "const float x0 = qx, y0 = qy, z0 = qz;"]
     assert body[4:] == [
         # consecutive sphere / box leaves share a bounding-sphere test: group record g follows the 4 program records
-        "const bool g0 = spec_any_near(live, spec_sphere_far(lp + 33, spec_sphere_a(lp + 33, x0, y0, z0), thrk));",
-        "const bool g1 = spec_any_near(live, spec_sphere_far(lp + 41, spec_sphere_a(lp + 41, x0, y0, z0), thrk));",
+        # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
+        "const bool g0 = spec_group_near(live, lp + 32, x0, y0, z0, thrk);",
+        "const bool g1 = spec_group_near(live, lp + 40, x0, y0, z0, thrk);",
         "float v0 = inf;",
         "if (g0)",
-        "{ const float a = spec_sphere_a(lp + 1, x0, y0, z0);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 1, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 1, a, tiny); } }",
+        "{ const float a = spec_sphere_a(lp + 0, x0, y0, z0);",
+        "if (spec_any_near(live, spec_sphere_far(lp + 0, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 0, a, tiny); } }",
         "float v1 = v0;",
         "if (g0)",
-        "{ const SpecBox b = spec_box_a(lp + 9, x0, y0, z0);",
+        "{ const SpecBox b = spec_box_a(lp + 8, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
         "if (g1)",
-        "{ const float a = spec_sphere_a(lp + 17, x0, y0, z0);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 17, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 17, a, tiny)); } }",
+        "{ const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
+        "if (spec_any_near(live, spec_sphere_far(lp + 16, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny)); } }",
         "float v3 = v2;",
         "if (g1)",
-        "{ const SpecBox b = spec_box_a(lp + 25, x0, y0, z0);",
+        "{ const SpecBox b = spec_box_a(lp + 24, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
         "__builtin_amdgcn_sched_barrier(0);",
         "return v3;",
@@ -83,7 +84,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
         line = line.strip()
         if line.startswith(("const float thr", "const float inf", "const float x0", "__builtin_amdgcn_sched_barrier")):
             continue
-        if re.match(r"const bool g\d+ = spec_any_near\(live, spec_sphere_far\(lp \+ \d+, spec_sphere_a\(lp \+ \d+, x0, y0, z0\), thrk\)\);$", line) \
+        if re.match(r"const bool g\d+ = spec_group_near\(live, lp \+ \d+, x0, y0, z0, thrk\);$", line) \
                 or re.match(r"if \(g\d+\)$", line):
             continue      # group tests: a group that is far implies each member is (tests/test_gpu_* check the spheres)
         if line.startswith("return"):
@@ -94,7 +95,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
             continue
         m = re.match(r"\{ const (?:float a = spec_sphere_a|SpecBox b = spec_box_a)\(lp \+ (\d+),", line)
         if m:
-            rec = (int(m.group(1)) - 1) // 8
+            rec = int(m.group(1)) // 8
             pending = sphere(rec) if "sphere" in line else box(rec)
             continue
         m = re.match(r"if \(spec_any_near\(.*?\)\) \{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \} \}", line)
@@ -243,19 +244,19 @@ def test_four_taps_in_one_pass_function(oracle):
                         "const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;",
                         "const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;",
                         "const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;"]
-    assert body[4:8] == ["const float v0_%d = spec_sphere<FAST>(lp + 1, x0_%d, y0_%d, z0_%d, tiny);" % (t, t, t, t) for t in range(4)]
-    assert body[8:12] == ["const float v1_%d = vmin(v0_%d, spec_box<FAST>(lp + 9, x0_%d, y0_%d, z0_%d, tiny));" % (t, t, t, t, t) for t in range(4)]
+    assert body[4:8] == ["const float v0_%d = spec_sphere<FAST>(lp + 0, x0_%d, y0_%d, z0_%d, tiny);" % (t, t, t, t) for t in range(4)]
+    assert body[8:12] == ["const float v1_%d = vmin(v0_%d, spec_box<FAST>(lp + 8, x0_%d, y0_%d, z0_%d, tiny));" % (t, t, t, t, t) for t in range(4)]
     assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
     pruned = taps_body(renderer.jit_source(cc, w, prune=True))
     k = pruned.index("float v0_0 = inf;")
-    assert pruned[k - 2:k] == ["const bool g0 = spec_any_near(live, spec_sphere_far(lp + 33, spec_sphere_a(lp + 33, cx, cy, cz), thrk));",
-                               "const bool g1 = spec_any_near(live, spec_sphere_far(lp + 41, spec_sphere_a(lp + 41, cx, cy, cz), thrk));"]
+    assert pruned[k - 2:k] == ["const bool g0 = spec_group_near(live, lp + 32, cx, cy, cz, thrk);",
+                               "const bool g1 = spec_group_near(live, lp + 40, cx, cy, cz, thrk);"]
     assert pruned[k:k + 10] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
-                                "if (g0 && spec_any_near(live, spec_sphere_far(lp + 1, spec_sphere_a(lp + 1, cx, cy, cz), thrk))) {",
-                                "v0_0 = spec_sphere<FAST>(lp + 1, x0_0, y0_0, z0_0, tiny);",
-                                "v0_1 = spec_sphere<FAST>(lp + 1, x0_1, y0_1, z0_1, tiny);",
-                                "v0_2 = spec_sphere<FAST>(lp + 1, x0_2, y0_2, z0_2, tiny);",
-                                "v0_3 = spec_sphere<FAST>(lp + 1, x0_3, y0_3, z0_3, tiny);", "}"]
+                                "if (g0 && spec_any_near(live, spec_sphere_far(lp + 0, spec_sphere_a(lp + 0, cx, cy, cz), thrk))) {",
+                                "v0_0 = spec_sphere<FAST>(lp + 0, x0_0, y0_0, z0_0, tiny);",
+                                "v0_1 = spec_sphere<FAST>(lp + 0, x0_1, y0_1, z0_1, tiny);",
+                                "v0_2 = spec_sphere<FAST>(lp + 0, x0_2, y0_2, z0_2, tiny);",
+                                "v0_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}"]
     # transforms: every scope gets four positions; smooth unions: no four-tap function
     cc, w = serialize(oracle, scenes.xform_mix())
     src = renderer.jit_source(cc, w)

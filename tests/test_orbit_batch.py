@@ -43,6 +43,40 @@ def test_ppm_files_and_resume_logic(tmp_path):
         orbit_batch.check_manifest(_args(tmp_path / "job", frames=7))
 
 
+def test_png_files_decode_to_the_pixels_and_resume(tmp_path):
+    """The PNG writer uses zlib only; the check decodes the file by hand (inflate + filter byte 0 per row)."""
+    import struct
+    import zlib
+    W, H = 13, 9
+    rng = np.random.default_rng(4)
+    img = rng.integers(0, 256, size=(H, W, 4), dtype=np.uint8)
+    p = orbit_batch.write_frame(str(tmp_path), 3, img, "png")
+    data = open(p, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    chunks, at = [], 8
+    while at < len(data):
+        n, kind = struct.unpack(">I4s", data[at:at + 8])
+        body = data[at + 8:at + 8 + n]
+        assert struct.unpack(">I", data[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body)
+        chunks.append((kind, body))
+        at += 12 + n
+    assert [k for k, _ in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    assert struct.unpack(">IIBBBBB", chunks[0][1]) == (W, H, 8, 2, 0, 0, 0)
+    raw = np.frombuffer(zlib.decompress(chunks[1][1]), dtype=np.uint8).reshape(H, 1 + 3 * W)
+    assert (raw[:, 0] == 0).all() and np.array_equal(raw[:, 1:].reshape(H, W, 3), img[..., :3])
+    try:
+        from PIL import Image
+        assert np.array_equal(np.asarray(Image.open(p).convert("RGB")), img[..., :3])
+    except ImportError:
+        pass
+    out = str(tmp_path)
+    assert orbit_batch.frames_todo(out, 6, 0, 1, W, H, "png") == [0, 1, 2, 4, 5]
+    with open(orbit_batch.frame_path(out, 4, "png"), "wb") as fh:             # truncated: not done
+        fh.write(data[:-5])
+    assert orbit_batch.frames_todo(out, 6, 0, 1, W, H, "png") == [0, 1, 2, 4, 5]
+    assert orbit_batch.frames_todo(out, 6, 0, 1, W + 1, H, "png") == [0, 1, 2, 3, 4, 5]   # other size: nothing matches
+
+
 def _args(out_dir, **kw):
     d = dict(out_dir=str(out_dir), frames=6, width=64, height=40, scene="g8", max_iter=64, format="ppm", slots=3, writers=2)
     d.update(kw)
@@ -80,7 +114,7 @@ def test_orbit_batch_with_the_32_node_graph(tmp_path, oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fmt", ["ppm", "f32"])
+@pytest.mark.parametrize("fmt", ["ppm", "png", "f32"])
 def test_orbit_batch_matches_the_oracle_and_resumes(tmp_path, oracle, fmt):
     a = _args(tmp_path, format=fmt)
     s = orbit_batch.render_batch(a, rank=0, world=1, device=0)
@@ -95,6 +129,8 @@ def test_orbit_batch_matches_the_oracle_and_resumes(tmp_path, oracle, fmt):
         if fmt == "ppm":
             body = data[len(orbit_batch.ppm_header(a.width, a.height)):]
             assert body == oracle.quantize_unorm8(ref)[..., :3].tobytes(), f
+        elif fmt == "png":
+            assert data == orbit_batch.png_bytes(oracle.quantize_unorm8(ref)), f
         else:
             assert data == ref.tobytes(), f
     # resume: remove one frame, truncate another -> exactly those two are rendered again

@@ -1,127 +1,152 @@
-// ubench_valu.hip -- per-instruction VALU issue throughput on gfx950 (wave64), to price the
-// instruction mix of the ray-marching interpreter.  Each kernel runs 8 independent dependency
-// chains per wave, 32 waves per CU (8 per SIMD), everything in registers.
+// ubench_valu.hip -- what one VALU instruction class costs a SIMD on gfx950 (wave64), in CYCLES at a MEASURED clock.
+//
+// Round 1 priced the march kernel's instruction mix with wall-clock rates converted at an assumed 2.4 GHz
+// ("v_add 2.77 cycles", against the 2 cycles MI355X_MICROARCH.md gives for a wave64 instruction on a SIMD-32).
+// A chip-wide loop of back-to-back vector instructions is exactly where DVFS lowers the clock, so this version
+// stamps every wave with s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop:
+//     cycles per wave-instruction per SIMD = median over waves of dt_cycles / (waves per SIMD x instructions per wave)
+//     clock                                = median over waves of dt_cycles / dt_realtime x 100 MHz
+// Each wave runs 8 independent dependency chains; a 256-thread block places one wave on each SIMD of a CU, and
+// `w` blocks per CU give w waves per SIMD.  Everything stays in registers (the LDS variant reads one broadcast dword).
+// Run it under `rocprofv3 --pmc GRBM_GUI_ACTIVE` as well: GRBM_GUI_ACTIVE / 8 / duration is the same clock seen from outside.
 // Build: hipcc --offload-arch=gfx950 -O3 -o build/ubench_valu tools/ubench_valu.hip
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
 
+enum Op { FMA, MUL, ADD, SUB_SGPR, SUB_ABS, MAX, MIN, MAX3, MAX_NEG, CMP_VCC, CMP_SGPR, CNDMASK, RSQ, RCP, SQRT, MOV, ADD_U32, MIN3_U32, XOR,
+          MIX_MAX_ADD, MIX_RSQ_3ADD, MIX_CMP_ADD, LDS_ADD, ADD_LITERAL, N_OPS };
+
 template <int OP>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
+__global__ __launch_bounds__(256) void k(unsigned long long* stamps, float* out, int iters, float seed) {
+    __shared__ float lds[64];
+    if (threadIdx.x < 64) lds[threadIdx.x] = seed + threadIdx.x;
+    __syncthreads();
     float a[8];
     for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 0.001f + i;
     float b = seed * 1.0001f, c = seed * 0.5f;
+    const float sb = __builtin_amdgcn_readfirstlane(__float_as_uint(b)) ? b : c;  // stays a VGPR; the "s" operand below is forced
+    (void)sb;
+    const __attribute__((address_space(3))) float* lp = (const __attribute__((address_space(3))) float*)lds;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     for (int it = 0; it < iters; it++) {
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-#define ONE(i)                                                                                            \
-    if (OP == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                    \
-    if (OP == 1) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                \
-    if (OP == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                \
-    if (OP == 3) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));                                            \
-    if (OP == 4) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                \
-    if (OP == 5) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                   \
-    if (OP == 6) asm volatile("v_cmp_lt_f32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc"); \
-    if (OP == 7) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                \
-    if (OP == 8) asm volatile("v_sub_f32 %0, |%0|, %1" : "+v"(a[i]) : "v"(b));                              \
-    if (OP == 9) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");               \
-    if (OP == 10) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");                   \
-    if (OP == 11) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));                                   \
-    if (OP == 12) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                  \
-    if (OP == 13) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "s"(b));                               \
-    if (OP == 14) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                               \
-    if (OP == 15) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+#define ONE(i)                                                                                                          \
+    if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                                \
+    if (OP == MUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                            \
+    if (OP == ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                            \
+    if (OP == SUB_SGPR) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "s"(seed));                                    \
+    if (OP == SUB_ABS) asm volatile("v_sub_f32 %0, |%0|, %1" : "+v"(a[i]) : "v"(b));                                      \
+    if (OP == MAX) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                            \
+    if (OP == MIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                            \
+    if (OP == MAX3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                              \
+    if (OP == MAX_NEG) asm volatile("v_max_f32 %0, %0, -%1" : "+v"(a[i]) : "v"(b));                                       \
+    if (OP == CMP_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");                            \
+    if (OP == CMP_SGPR) { unsigned long long m; asm volatile("v_cmp_lt_f32 %0, %1, %2" : "=s"(m) : "v"(a[i]), "v"(b)); }  \
+    if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b));                               \
+    if (OP == RSQ) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));                                                         \
+    if (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));                                                         \
+    if (OP == SQRT) asm volatile("v_sqrt_f32 %0, %0" : "+v"(a[i]));                                                       \
+    if (OP == MOV) asm volatile("v_mov_b32 %0, %1" : "+v"(a[i]) : "v"(b));                                                \
+    if (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                        \
+    if (OP == MIN3_U32) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));                          \
+    if (OP == XOR) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                                            \
+    if (OP == MIX_MAX_ADD) { if ((i & 1) == 0) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));                \
+                             else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }                           \
+    if (OP == MIX_RSQ_3ADD) { if ((i & 3) == 0) asm volatile("v_rsq_f32 %0, %0" : "+v"(a[i]));                            \
+                              else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }                          \
+    if (OP == MIX_CMP_ADD) { if ((i & 1) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");    \
+                             else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }                           \
+    if (OP == LDS_ADD) { float p = lp[(i + r) & 63]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(p)); }        \
+    if (OP == ADD_LITERAL) asm volatile("v_add_f32 %0, 0x3f8ccccd, %0" : "+v"(a[i]));
             REP8(ONE)
 #undef ONE
         }
     }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     float s = 0;
     for (int i = 0; i < 8; i++) s += a[i];
     out[blockIdx.x * 256 + threadIdx.x] = s;
-}
-// packed: 4 chains of float2
-__global__ __launch_bounds__(256) void k_pk(float* out, int iters, float seed, int op) {
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 a[8];
-    for (int i = 0; i < 8; i++) a[i] = f2{seed + threadIdx.x * 0.001f + i, seed + i};
-    f2 b{seed * 1.0001f, seed}, c{seed * 0.5f, seed};
-    for (int it = 0; it < iters; it++) {
-#pragma unroll
-        for (int r = 0; r < 8; r++) {
-#define ONE(i)                                                                                  \
-    if (op == 0) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));       \
-    else if (op == 1) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));              \
-    else asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
-            REP8(ONE)
-#undef ONE
-        }
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* st = stamps + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
+        st[0] = t0; st[1] = t1; st[2] = r0; st[3] = r1;
     }
-    float s = 0;
-    for (int i = 0; i < 8; i++) s += a[i].x + a[i].y;
-    out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+struct Result { double cycles_per_inst, clock_ghz, wall_ns_per_inst; };
+
 template <int OP>
-int run(const char* name, float* d, int instr_per_one, int waves_per_simd) {
-    int cus = 256;
-    int blocks = cus * waves_per_simd;  // 256-thread blocks = 4 waves -> one per SIMD each
-    const int iters = 2000;
+int run(const char* name, unsigned long long* d_st, float* d_out, int n_cu, int w, const char* note = "") {
+    const int blocks = n_cu * w, iters = 4000;
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, 10, 1.0f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_st, d_out, 200, 1.0f);  // warm
     CHK(hipDeviceSynchronize());
     CHK(hipEventRecord(e0, 0));
-    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d, iters, 1.0f);
+    hipLaunchKernelGGL(k<OP>, dim3(blocks), dim3(256), 0, 0, d_st, d_out, iters, 1.0f);
     CHK(hipEventRecord(e1, 0));
     CHK(hipEventSynchronize(e1));
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-    double instr_per_wave = (double)iters * 64 * instr_per_one;
-    double per_simd = instr_per_wave * waves_per_simd;   // wave-instructions per SIMD
-    double ns_per_instr = ms * 1e6 / per_simd;
-    printf("%-28s waves/SIMD %d  %.3f ns per wave-instr per SIMD  (= %.2f cycles at 2.4 GHz)  chip %.1f G wave-instr/s\n",
-           name, waves_per_simd, ns_per_instr, ns_per_instr * 2.4, 1024.0 / ns_per_instr);
+    std::vector<unsigned long long> st((size_t)blocks * 16);
+    CHK(hipMemcpy(st.data(), d_st, st.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> cyc, clk;
+    for (int wv = 0; wv < blocks * 4; wv++) {
+        const double dc = (double)(st[4 * wv + 1] - st[4 * wv]), dr = (double)(st[4 * wv + 3] - st[4 * wv + 2]);
+        cyc.push_back(dc);
+        if (dr > 0) clk.push_back(dc / dr * 0.1);  // cycles per 10 ns -> GHz
+    }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    const double n_inst = (double)iters * 64;
+    const double med_cyc = cyc[cyc.size() / 2], med_clk = clk.empty() ? 0.0 : clk[clk.size() / 2];
+    printf("%-30s waves/SIMD %d  %6.2f cycles per wave-instr per SIMD  clock %.2f GHz  (wall %.3f ns per instr per SIMD)%s\n",
+           name, w, med_cyc / (w * n_inst), med_clk, ms * 1e6 / (n_inst * w), note);
     return 0;
 }
 
-int main() {
-    float* d;
-    CHK(hipMalloc(&d, 256 * 8 * 256 * sizeof(float) * 4));
-    for (int w : {8, 4, 2, 1}) {
-        run<0>("v_fma_f32", d, 1, w);
-    }
-    run<1>("v_mul_f32", d, 1, 8);
-    run<2>("v_add_f32", d, 1, 8);
-    run<3>("v_sqrt_f32", d, 1, 8);
-    run<15>("v_rcp_f32", d, 1, 8);
-    run<4>("v_max_f32", d, 1, 8);
-    run<5>("v_max3_f32", d, 1, 8);
-    run<6>("v_cmp+v_cndmask pair", d, 2, 8);
-    run<10>("v_cmp_lt_f32", d, 1, 8);
-    run<9>("v_cndmask_b32", d, 1, 8);
-    run<7>("v_add_u32", d, 1, 8);
-    run<8>("v_sub_f32 |abs|", d, 1, 8);
-    run<11>("v_mov_b32", d, 1, 8);
-    run<12>("v_min3_u32", d, 1, 8);
-    run<13>("v_sub_f32 sgpr operand", d, 1, 8);
-    run<14>("v_xor_b32", d, 1, 8);
-    // packed
-    for (int op = 0; op < 3; op++) {
-        hipEvent_t e0, e1;
-        CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
-        const int iters = 2000, w = 8;
-        hipLaunchKernelGGL(k_pk, dim3(256 * w), dim3(256), 0, 0, d, 10, 1.0f, op);
-        CHK(hipDeviceSynchronize());
-        CHK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(k_pk, dim3(256 * w), dim3(256), 0, 0, d, iters, 1.0f, op);
-        CHK(hipEventRecord(e1, 0));
-        CHK(hipEventSynchronize(e1));
-        float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-        double ns = ms * 1e6 / ((double)iters * 64 * w);
-        printf("%-28s waves/SIMD %d  %.3f ns per wave-instr per SIMD  (= %.2f cycles at 2.4 GHz)\n",
-               op == 0 ? "v_pk_fma_f32" : op == 1 ? "v_pk_mul_f32" : "v_pk_add_f32", w, ns, ns * 2.4);
+int main(int argc, char** argv) {
+    hipDeviceProp_t prop;
+    CHK(hipGetDeviceProperties(&prop, 0));
+    const int n_cu = prop.multiProcessorCount;
+    unsigned long long* d_st;
+    float* d_out;
+    CHK(hipMalloc(&d_st, (size_t)n_cu * 8 * 16 * 8));
+    CHK(hipMalloc(&d_out, (size_t)n_cu * 8 * 256 * 4));
+    printf("# %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime (100 MHz); median over waves\n", prop.gcnArchName, n_cu);
+    const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+    for (int w : {8, 5, 4, 2, 1}) run<FMA>("v_fma_f32", d_st, d_out, n_cu, w);
+    for (int w : {8, 5}) {
+        run<ADD>("v_add_f32", d_st, d_out, n_cu, w);
+        run<MUL>("v_mul_f32", d_st, d_out, n_cu, w);
+        run<SUB_SGPR>("v_sub_f32 (sgpr operand)", d_st, d_out, n_cu, w);
+        run<SUB_ABS>("v_sub_f32 |abs| modifier", d_st, d_out, n_cu, w);
+        run<ADD_LITERAL>("v_add_f32 (32-bit literal)", d_st, d_out, n_cu, w);
+        run<MAX>("v_max_f32", d_st, d_out, n_cu, w);
+        run<MIN>("v_min_f32", d_st, d_out, n_cu, w);
+        run<MAX_NEG>("v_max_f32 (neg modifier)", d_st, d_out, n_cu, w);
+        run<MAX3>("v_max3_f32", d_st, d_out, n_cu, w);
+        run<CMP_VCC>("v_cmp_lt_f32 -> vcc", d_st, d_out, n_cu, w);
+        run<CMP_SGPR>("v_cmp_lt_f32 -> sgpr pair", d_st, d_out, n_cu, w);
+        run<CNDMASK>("v_cndmask_b32 (vcc)", d_st, d_out, n_cu, w);
+        run<MOV>("v_mov_b32", d_st, d_out, n_cu, w);
+        run<ADD_U32>("v_add_u32", d_st, d_out, n_cu, w);
+        run<MIN3_U32>("v_min3_u32", d_st, d_out, n_cu, w);
+        run<XOR>("v_xor_b32", d_st, d_out, n_cu, w);
+        run<RSQ>("v_rsq_f32", d_st, d_out, n_cu, w);
+        run<RCP>("v_rcp_f32", d_st, d_out, n_cu, w);
+        run<SQRT>("v_sqrt_f32", d_st, d_out, n_cu, w);
+        run<MIX_MAX_ADD>("mix: v_max, v_add alternating", d_st, d_out, n_cu, w, "  [per instruction of the mix]");
+        run<MIX_CMP_ADD>("mix: v_cmp, v_add alternating", d_st, d_out, n_cu, w, "  [per instruction of the mix]");
+        run<MIX_RSQ_3ADD>("mix: v_rsq + 3 v_add", d_st, d_out, n_cu, w, "  [per instruction of the mix]");
+        run<LDS_ADD>("ds_read_b32 (broadcast) + v_add", d_st, d_out, n_cu, w, "  [per v_add; one LDS read each]");
+        if (quick) break;
     }
     return 0;
 }
