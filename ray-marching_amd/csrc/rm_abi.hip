@@ -258,7 +258,7 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
         const bool prune = c->decoded.prunable &&
                            (c->prune == 1 || (c->prune == 2 && c->decoded.n_sphere + c->decoded.n_box >= kPruneLeaves));
-        c->spec = rmjit::Cache::get().request(c->decoded.rec, wpt, prune, c->decoded.has_materials);
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, c->decoded.mrec, wpt, prune);
         c->spec_pruned = prune;
         c->spec_gen = c->prog_gen;
         c->spec_wpt = wpt;
@@ -354,7 +354,9 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     hipFunction_t spec_fn = lds ? specialised_kernel(c, WPT) : nullptr;
     if (spec_fn) L.spill_depth = 0u;
     // the material evaluation of a tagged program borrows the spill area: (distance, index) pairs + saved positions
-    if (L.n_mrec != 0u) L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
+    // (a specialised kernel with the generated material walk keeps those pairs in registers too)
+    if (L.n_mrec != 0u && !(spec_fn && c->spec && c->spec->material_walk))
+        L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
     const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms) +
@@ -1059,7 +1061,7 @@ int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int 
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return rc;
-    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, wpt, prune && d.prunable, d.has_materials, src)) return RM_ERR_ARG;
+    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, d.mrec, wpt, prune && d.prunable, src)) return RM_ERR_ARG;
     return RM_OK;
 }
 void copy_out(const std::string& s, char* buf, size_t cap) {

@@ -221,6 +221,8 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
                 if (depth + 1 > 32) return RM_ERR_STACK_OVERFLOW;  // the reference machine peaks one higher
                 if (depth + 1 > d.max_depth) d.max_depth = depth + 1;
                 r.op = RM_OP(kind, mode, 0);
+                if ((kind == RM_KIND_SPHERE || kind == RM_KIND_BOX) && (mode == RM_MODE_UNION || mode == RM_MODE_SUB))
+                    r.op |= ((kind == RM_KIND_SPHERE ? 1u : 2u) + (mode == RM_MODE_SUB ? 2u : 0u)) << 16;  // RM_OP_FASTCLASS
             } else {
                 uint32_t spill = depth >= 1 ? 1u : 0u;  // a live accumulator must be saved
                 if (spill) { spilled++; if (spilled > d.spill_depth) d.spill_depth = spilled; }

@@ -21,7 +21,7 @@
 // The arithmetic performed on each value is exactly the reference's, in the same order;
 // only the bookkeeping (where a value lives) changes.
 struct RmRecord {
-    uint32_t op;  // kind | mode<<3 | spill<<6
+    uint32_t op;  // kind | mode<<3 | spill<<6 | fast class<<16
     float p[7];   // sphere: cx cy cz r [r * 1.000005, for specialised kernels]   box: cx cy cz rx ry rz   cylinder: cx cy cz r half_h
                   // plane: nx ny nz h    POP+SMOOTH: k            p[6] (primitives): slot in the miss-test tables
 };
@@ -38,6 +38,11 @@ enum : uint32_t { RM_MAX_XFORM_DEPTH = 8 };
 #define RM_OP_KIND(op) ((op) & 7u)
 #define RM_OP_MODE(op) (((op) >> 3) & 7u)
 enum : uint32_t { RM_OP_SPILL = 1u << 6 };
+// Interpreter fast class (bits 16-18; generated code and the v1 kernel ignore it): the four record shapes that make up a
+// left-deep chain -- a sphere / box leaf fused with the Union / Subtraction that consumes it, on a live accumulator, no
+// stack traffic -- are dispatched with two decisions instead of the generic kind / spill / mode ladder (rm_interp.h).
+//   0 generic   1 sphere + union   2 box + union   3 sphere + subtraction   4 box + subtraction
+#define RM_OP_FASTCLASS(op) (((op) >> 16) & 7u)
 
 // reference opcodes (csg/builder.rs:1-24)
 enum : uint32_t { RM_CMD_SPHERE = 0, RM_CMD_BOX = 1, RM_CMD_UNION = 100, RM_CMD_SUBTRACTION = 101 };

@@ -118,6 +118,18 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
     op = __builtin_amdgcn_readfirstlane(op);
+    // The records of a left-deep chain (RM_OP_FASTCLASS): leaf, then min / max(., -leaf) into the accumulator; no stack slot
+    // is read or written, nothing merges with the generic path below (whose value copies at the joins of its kind / spill /
+    // mode ladder cost ~6 v_mov, ~8 branches and ~20 scalar instructions per record).
+    const uint32_t cls = RM_OP_FASTCLASS(op);
+    if (cls != 0u) {
+#pragma unroll
+        for (int k = 0; k < R; k++) {
+            const float b = (cls & 1u) ? sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny) : sdf_box_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
+            acc[k] = cls >= 3u ? vmax_negb(acc[k], b) : vmin(acc[k], b);  // wgsl:248-252 / :242-246
+        }
+        return;
+    }
     const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
     if constexpr (EXT) {
         if (kind == RM_KIND_XFORM) {  // extension: the evaluation position changes; saved positions live in LDS
@@ -234,6 +246,16 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
 #endif
 #pragma unroll
     for (int k = 0; k < R; k++) out[k] = acc[k];
+}
+
+// SmoothUnion as the material walks apply it (exec_command, RM_MODE_SMOOTH): every lane takes the full form.
+RM_DEV float material_smooth_union(float kk, float a, float b) {
+    float v = fmin_(a, b);
+    if (kk > 0.0f) {
+        const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) / kk;
+        v = v - ((h * h) * kk) * 0.25f;
+    }
+    return v;
 }
 
 // Materials (extension; semantics: oracle/rm_oracle.c map_scene_impl with mat_out).  One evaluation of the material

@@ -109,7 +109,7 @@ inline std::string structure_key(const std::vector<RmRecord>& rec) {
     std::string k;
     k.reserve(rec.size() * 2);
     for (const RmRecord& r : rec) {
-        k.push_back("PSBCLX??"[RM_OP_KIND(r.op)]);
+        k.push_back("PSBCLXM?"[RM_OP_KIND(r.op)]);
         k.push_back("pusixy??"[RM_OP_MODE(r.op)]);
     }
     return k;
@@ -122,6 +122,12 @@ inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty
 // named values.  With `prune`, sphere and box leaves are wrapped in the wave-uniform far test of
 // rm_kernel_v5.h ("Pruning").  Returns false if the records do not form a valid program (cannot
 // happen for the output of rm_decode_program).
+// A/B knobs of the generated code (environment, read when a structure is generated; defaults are the measured best)
+inline int jit_knob(const char* name, int dflt) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : dflt;
+}
+
 inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
     const bool count = prune && std::getenv("RM_JIT_PRUNE_STATS") != nullptr;  // diagnostics: count evaluated leaves
     std::string s;
@@ -272,6 +278,7 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
         s += "    const float thr2k = (thr * thr) * 1.00001f;\n";
         s += "    const float inf = __uint_as_float(0x7F800000u);\n";
     }
+    const bool fence = jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;  // A/B: see guard_fence (rm_kernel_v5.h)
     s += "    const float e = 0.0001f;\n";  // wgsl:136; k = (1,-1): taps (+,-,-), (-,-,+), (-,+,-), (+,+,+) (wgsl:138-141)
     s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
     s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
@@ -334,8 +341,22 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
             const int b = stack.back(); stack.pop_back();
             const int a = stack.back(); stack.pop_back();
             const int w = nv++;
-            // SmoothUnion: four copies of its division need ~130 VGPRs (3 waves per SIMD): 40 % slower than tapping one
-            // position at a time (measured); such programs keep the one-position taps
+            if (mode == RM_MODE_SMOOTH) {
+                // SmoothUnion: left to itself the compiler interleaves the four copies of the correctly rounded division
+                // (~130 VGPRs, 3 waves per SIMD: 40 % slower than tapping one position at a time); spec_smooth_union4
+                // tests the blend zone once for the four taps and keeps one division in flight.
+                // RM_JIT_TAPS4_SMOOTH=0 restores the one-position taps.
+                const char* knob = std::getenv("RM_JIT_TAPS4_SMOOTH");
+                if (knob && std::atoi(knob) == 0) return false;
+                std::snprintf(line, sizeof line,
+                              "    float v%d_0, v%d_1, v%d_2, v%d_3;\n"
+                              "    { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3}, sb[4] = {v%d_0, v%d_1, v%d_2, v%d_3}; float so[4];\n"
+                              "      spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
+                              w, w, w, w, a, a, a, a, b, b, b, b, off, w, w, w, w);
+                s += line;
+                stack.push_back(w);
+                continue;
+            }
             if (!op) return false;
             for (int t = 0; t < 4; t++) {
                 std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, v%d_%d);\n", w, t, op, a, t, b, t);
@@ -385,6 +406,7 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
             s += line;
         }
         if (pruned) s += "    }\n";
+        if (fence && kind != RM_KIND_PLANE) s += "    guard_fence(tiny);\n";  // see guard_fence (rm_kernel_v5.h)
         stack.push_back(w);
         if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
     }
@@ -398,11 +420,131 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
     return true;
 }
 
+
+// The material walk of a tagged program (rm_interp.h map_scene_material) as straight-line code: one evaluation of the
+// program WITH its Material tags at the position of a hit, every value a (distance, index) pair of named variables --
+// no stack in LDS, no decode.  Distances go through the operations map_scene_material applies (generic sqrt, the
+// interpreter's leaf functions and operators), indices through its selection rules: primitives carry 0, a tag overwrites
+// the index of the value on top, an operator keeps the index of the operand that decides its result (Union / SmoothUnion
+// b < a, Subtraction -b > a, Intersection b > a take b's; ties and NaN a's).  Parameters -- tag indices included -- are
+// read from the device copy of the tagged records (uniform addresses: scalar loads), so they stay data.
+inline bool generate_material_walk(const std::vector<RmRecord>& mrec, std::string* out) {
+    std::string s;
+    char line[768];
+    s += "namespace rmk {\n";
+    s += "RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz) {\n";
+    s += "    SqrtGuard unused;\n";
+    s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
+    std::vector<int> stack, pos;
+    pos.push_back(0);
+    int nv = 0, np = 0;
+    for (size_t i = 0; i < mrec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(mrec[i].op), mode = RM_OP_MODE(mrec[i].op);
+        const unsigned r = (unsigned)i;
+        if (kind == RM_KIND_MATERIAL) {  // tags the value on top
+            if (stack.empty()) return false;
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            std::snprintf(line, sizeof line, "    const float v%d = v%d; const uint32_t m%d = __float_as_uint(mp[%u].p[0]);\n", w, a, w, r);
+            s += line;
+            stack.push_back(w);
+            continue;
+        }
+        if (kind == RM_KIND_XFORM) {
+            const int c = pos.back();
+            if ((mode & 1u) == 0u) {
+                const int n = ++np;
+                if (mode == RM_XF_T_PUSH)
+                    std::snprintf(line, sizeof line, "    const float x%d = x%d - mp[%u].p[0], y%d = y%d - mp[%u].p[1], z%d = z%d - mp[%u].p[2];\n", n, c, r, n, c, r, n, c, r);
+                else if (mode == RM_XF_R_PUSH)
+                    std::snprintf(line, sizeof line, "    float x%d = x%d, y%d = y%d, z%d = z%d; xf_rotate_conj(mp[%u].p[0], mp[%u].p[1], mp[%u].p[2], mp[%u].p[3], x%d, y%d, z%d);\n",
+                                  n, c, n, c, n, c, r, r, r, r, n, n, n);
+                else
+                    std::snprintf(line, sizeof line, "    const float x%d = x%d / mp[%u].p[0], y%d = y%d / mp[%u].p[0], z%d = z%d / mp[%u].p[0];\n", n, c, r, n, c, r, n, c, r);
+                s += line;
+                pos.push_back(n);
+            } else {
+                if (pos.size() < 2 || stack.empty()) return false;
+                pos.pop_back();
+                if (mode == RM_XF_S_POP) {
+                    const int a = stack.back(); stack.pop_back();
+                    const int w = nv++;
+                    std::snprintf(line, sizeof line, "    const float v%d = v%d * mp[%u].p[0]; const uint32_t m%d = m%d;\n", w, a, r, w, a);
+                    s += line;
+                    stack.push_back(w);
+                }
+            }
+            continue;
+        }
+        // binary operator on (a, b): value expression and the "b decides" predicate, as map_scene_material
+        auto combine = [&](int w, const char* a, const char* am, const char* b, const char* bm) -> bool {
+            if (mode == RM_MODE_UNION)
+                std::snprintf(line, sizeof line, "    const float v%d = vmin(%s, %s); const uint32_t m%d = %s < %s ? %s : %s;\n", w, a, b, w, b, a, bm, am);
+            else if (mode == RM_MODE_SUB)
+                std::snprintf(line, sizeof line, "    const float v%d = vmax_negb(%s, %s); const uint32_t m%d = -%s > %s ? %s : %s;\n", w, a, b, w, b, a, bm, am);
+            else if (mode == RM_MODE_INTER)
+                std::snprintf(line, sizeof line, "    const float v%d = fmax_(%s, %s); const uint32_t m%d = %s > %s ? %s : %s;\n", w, a, b, w, b, a, bm, am);
+            else if (mode == RM_MODE_SMOOTH)
+                std::snprintf(line, sizeof line, "    const float v%d = material_smooth_union(mp[%u].p[0], %s, %s); const uint32_t m%d = %s < %s ? %s : %s;\n",
+                              w, r, a, b, w, b, a, bm, am);
+            else
+                return false;
+            s += line;
+            return true;
+        };
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2) return false;
+            const int b = stack.back(); stack.pop_back();
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            char an[16], am[16], bn[16], bm[16];
+            std::snprintf(an, sizeof an, "v%d", a); std::snprintf(am, sizeof am, "m%d", a);
+            std::snprintf(bn, sizeof bn, "v%d", b); std::snprintf(bm, sizeof bm, "m%d", b);
+            if (!combine(w, an, am, bn, bm)) return false;
+            stack.push_back(w);
+            continue;
+        }
+        const char* fn = kind == RM_KIND_SPHERE ? "sdf_sphere_t<false>" : kind == RM_KIND_BOX ? "sdf_box_t<false>"
+                       : kind == RM_KIND_CYLINDER ? "sdf_cylinder_t<false>" : nullptr;
+        const int c = pos.back();
+        const int leaf = nv++;  // the leaf's own value; its index is 0
+        if (fn) std::snprintf(line, sizeof line, "    const float v%d = %s(x%d, y%d, z%d, mp[%u].p, unused);\n", leaf, fn, c, c, c, r);
+        else if (kind == RM_KIND_PLANE)
+            std::snprintf(line, sizeof line, "    const float v%d = ((x%d * mp[%u].p[0] + y%d * mp[%u].p[1]) + z%d * mp[%u].p[2]) + mp[%u].p[3];\n", leaf, c, r, c, r, c, r, r);
+        else return false;
+        s += line;
+        if (mode == RM_MODE_PUSH) {
+            std::snprintf(line, sizeof line, "    const uint32_t m%d = 0u;\n", leaf);
+            s += line;
+            stack.push_back(leaf);
+        } else {  // leaf fused with the operator that consumes it: a = accumulator, b = leaf (index 0)
+            if (stack.empty() || mode == RM_MODE_SMOOTH) return false;
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            char an[16], am[16], bn[16];
+            std::snprintf(an, sizeof an, "v%d", a); std::snprintf(am, sizeof am, "m%d", a); std::snprintf(bn, sizeof bn, "v%d", leaf);
+            if (!combine(w, an, am, bn, "0u")) return false;
+            stack.push_back(w);
+        }
+    }
+    if (stack.empty()) return false;
+    std::snprintf(line, sizeof line, "    return m%d;\n}\n}  // namespace rmk\n", stack.back());
+    s += line;
+    *out = std::move(s);
+    return true;
+}
+
 inline const char* kernel_name() { return "rm_render_v5_spec"; }
 
-inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prune, bool materials, std::string* out) {
-    std::string body, taps;
+// mrec: the program decoded with its Material tags (empty for an untagged program): the kernel then gets the material
+// phase, with the walk generated as code when jit_knob RM_JIT_MATERIAL_WALK allows (default) and possible.
+inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, bool prune, std::string* out,
+                            bool* walk_generated = nullptr) {
+    const bool materials = !mrec.empty();
+    std::string body, taps, walk;
     if (!generate_map_scene(rec, prune, &body)) return false;
+    const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
+    if (walk_generated) *walk_generated = walk_spec;
     const char* taps_knob = std::getenv("RM_JIT_TAPS4");  // A/B: RM_JIT_TAPS4=0 keeps the taps on map_scene_spec
     const bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0) && generate_map_scene_taps(rec, prune, &taps);
     std::string s;
@@ -414,6 +556,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     s += "#define RM_JIT_TU 1\n";
     if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
+    if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
     if (const char* pr = std::getenv("RM_JIT_PRIO_LONG_RAYS")) {  // experiment knob
         s += "#define RM_PRIO_LONG_RAYS ";
         s += std::to_string(std::atoi(pr));
@@ -422,6 +565,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, int wpt, bool prun
     s += "#include \"rm_kernel_v5.h\"\n";
     s += body;
     if (taps4) s += taps;
+    if (walk_spec) s += walk;
     char line[512];
     if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) {  // experiment knob: cap the VGPR budget
         std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", std::atoi(w), std::atoi(w));
@@ -557,6 +701,7 @@ struct Entry {
     std::vector<char> code;  // gfx950 code object
     std::string log;
     double compile_ms = 0.0;
+    bool material_walk = false;  // the kernel carries the generated material walk (it needs no LDS stack for the material phase)
     std::string cached_source;  // non-empty iff `code` came from the disk cache: if the loader rejects it, the file is
                                 // dropped and this source compiled afresh, once (rm_abi.hip specialised_kernel)
     // Filled by the caller's (HIP) thread under `m`: device ordinal -> {hipModule_t, hipFunction_t}.
@@ -591,8 +736,9 @@ public:
     // The entry for (rec structure, wpt); queues its compilation for the worker thread the first time.
     // materials: the program carries Material tags (the kernel gets the material phase; the structure is that of
     // the untagged program)
-    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, int wpt, bool prune, bool materials) {
-        const std::string key = std::to_string(wpt) + (prune ? "p" : "") + (materials ? "m:" : ":") + structure_key(rec);
+    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, bool prune) {
+        // a tagged program's kernel also depends on where its tags sit (the material walk is generated from mrec)
+        const std::string key = std::to_string(wpt) + (prune ? "p" : "") + ":" + structure_key(rec) + (mrec.empty() ? "" : "|m:" + structure_key(mrec));
         std::unique_lock<std::mutex> lk(m_);
         auto it = entries_.find(key);
         if (it != entries_.end()) return it->second;
@@ -604,7 +750,7 @@ public:
         entries_[key] = e;
         Job job;
         job.entry = e;
-        if (!generate_source(rec, wpt, prune, materials, &job.source)) {
+        if (!generate_source(rec, mrec, wpt, prune, &job.source, &e->material_walk)) {
             e->state = Entry::FAILED;
             e->log = "program structure could not be turned into code";
             return e;

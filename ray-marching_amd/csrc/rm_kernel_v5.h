@@ -51,6 +51,11 @@ RM_DEV LdsF lds_vector_base(const void* generic_lds_ptr) {
 // `live`: wave mask of the lanes whose value will be used (far tests ignore the others)
 template <bool FAST>
 RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval);
+#ifdef RM_JIT_MATERIAL_WALK
+// The material walk of a tagged program as straight-line code (rm_jit.h generate_material_walk): which material does the
+// surface at (x, y, z) carry.  mp: the tagged records in device memory (uniform addresses: scalar loads).
+RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz);
+#endif
 #ifdef RM_JIT_TAPS4
 // The four normal taps of a hit at c in one pass (rm_jit.h generate_map_scene_taps): f[t] = map_scene(c + k_t eps).
 template <bool FAST>
@@ -175,6 +180,37 @@ RM_DEV float spec_smooth_union(LdsF r, float a, float b, unsigned long long live
         v = v - ((h * h) * kk) * 0.25f;
     }
     return v;
+}
+
+// Pins the running minimum / maximum of a SqrtGuard at this point of the generated code.  The guard folds the bit pattern
+// of every sqrt argument of an evaluation into two integers; integer min / max may be reassociated, and the compiler
+// rebuilt the sequential updates of the four-tap function (64 arguments for a 16-leaf program) into trees that combine
+// the FIRST arguments LAST -- every argument stayed live to the end: +55 VGPRs, the difference between 6 and 3-4 waves
+// per SIMD for the smooth-min and material scenes (round 1 blamed the four copies of SmoothUnion's division and kept such
+// programs on one-position taps).  Measured on the smooth-min scene at 4K: 15.6 ms without the fence, 11.6 ms with it.
+RM_DEV void guard_fence(SqrtGuard& g) { asm("" : "+v"(g.lo), "+v"(g.hi)); }
+
+// The same operator applied to the four tap values of a hit (map_scene_taps): ONE wave-uniform "is any live lane of any
+// tap inside the blend zone" test for the four.  A lane outside the zone has h = 0 and gets v - 0 = v: the value the
+// skipping form returns.
+RM_DEV void spec_smooth_union4(LdsF r, const float (&a)[4], const float (&b)[4], unsigned long long live, float (&out)[4]) {
+    const float kk = r[0];
+    float t[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        out[i] = fmin_(a[i], b[i]);
+        t[i] = kk - __builtin_fabsf(a[i] - b[i]);
+    }
+    if (!(kk > 0.0f)) return;
+    const unsigned long long in_zone = (__builtin_amdgcn_ballot_w64(t[0] > 0.0f) | __builtin_amdgcn_ballot_w64(t[1] > 0.0f)) |
+                                       (__builtin_amdgcn_ballot_w64(t[2] > 0.0f) | __builtin_amdgcn_ballot_w64(t[3] > 0.0f));
+    if (kk < __uint_as_float(0x7F800000u) && (in_zone & live) == 0ull) return;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const float h = fmax_(t[i], 0.0f) / kk;
+        out[i] = out[i] - ((h * h) * kk) * 0.25f;
+        __builtin_amdgcn_sched_barrier(0);  // one correctly rounded division in flight: interleaved, the four need ~60 more VGPRs
+    }
 }
 
 constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
@@ -519,7 +555,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             if (tap_t == 4u) {  // the normals of this batch are complete (tn): which material does each hit carry?
                 const uint32_t e = hq_n + lane;
                 const float hx = hq_v[e], hy = hq_v[V5_HQ + e], hz = hq_v[2u * V5_HQ + e];
+#ifdef RM_JIT_MATERIAL_WALK
+                const uint32_t m = map_scene_material_spec(L.mprog, hx, hy, hz);
+#else
                 const uint32_t m = map_scene_material(L.mprog, L.n_mrec, spill, L.mat_value_depth, hx, hy, hz);
+#endif
                 if (lane < tap_n) {
                     const uint32_t r = hq_rid[e] & 1023u;
                     res[r] = shade_hit(tn[lane], tn[64u + lane], tn[128u + lane], hx, hy, hz);  // wgsl:98-103

@@ -245,7 +245,8 @@ def test_four_taps_in_one_pass_function(oracle):
                         "const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;",
                         "const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;"]
     assert body[4:8] == ["const float v0_%d = spec_sphere<FAST>(lp + 0, x0_%d, y0_%d, z0_%d, tiny);" % (t, t, t, t) for t in range(4)]
-    assert body[8:12] == ["const float v1_%d = vmin(v0_%d, spec_box<FAST>(lp + 8, x0_%d, y0_%d, z0_%d, tiny));" % (t, t, t, t, t) for t in range(4)]
+    assert body[8] == "guard_fence(tiny);"       # pins the sqrt guard after every leaf (register pressure: rm_kernel_v5.h)
+    assert body[9:13] == ["const float v1_%d = vmin(v0_%d, spec_box<FAST>(lp + 8, x0_%d, y0_%d, z0_%d, tiny));" % (t, t, t, t, t) for t in range(4)]
     assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
     pruned = taps_body(renderer.jit_source(cc, w, prune=True))
     k = pruned.index("float v0_0 = inf;")
@@ -257,11 +258,12 @@ def test_four_taps_in_one_pass_function(oracle):
                                 "v0_1 = spec_sphere<FAST>(lp + 0, x0_1, y0_1, z0_1, tiny);",
                                 "v0_2 = spec_sphere<FAST>(lp + 0, x0_2, y0_2, z0_2, tiny);",
                                 "v0_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}"]
-    # transforms: every scope gets four positions; smooth unions: no four-tap function
+    assert pruned[k + 10] == "guard_fence(tiny);"
+    # transforms: every scope gets four positions; smooth unions: the four blends behind ONE blend-zone test
     cc, w = serialize(oracle, scenes.xform_mix())
     src = renderer.jit_source(cc, w)
     assert "#define RM_JIT_TAPS4 1" in src and "x1_3" in "\n".join(taps_body(src))
     for scene in (scenes.g32s(), scenes.ext_mix()):
         cc, w = serialize(oracle, scene)
         src = renderer.jit_source(cc, w)
-        assert "RM_JIT_TAPS4" not in src and "map_scene_taps(" not in src.split('#include "rm_kernel_v5.h"')[1]
+        assert "#define RM_JIT_TAPS4 1" in src and "spec_smooth_union4(lp + " in "\n".join(taps_body(src))

@@ -4,8 +4,11 @@
 // ("v_add 2.77 cycles", against the 2 cycles MI355X_MICROARCH.md gives for a wave64 instruction on a SIMD-32).
 // A chip-wide loop of back-to-back vector instructions is exactly where DVFS lowers the clock, so this version
 // stamps every wave with s_memtime (shader cycles) and s_memrealtime (100 MHz) around its loop:
-//     cycles per wave-instruction per SIMD = median over waves of dt_cycles / (waves per SIMD x instructions per wave)
 //     clock                                = median over waves of dt_cycles / dt_realtime x 100 MHz
+//     cycles per wave-instruction per SIMD = kernel duration (HIP events) x clock / (waves per SIMD x instructions per wave)
+// (a wave's own dt_cycles is NOT the kernel's: the SIMD issues oldest-first, so the eight waves of a SIMD finish one
+// after the other and each is resident for about a third of the kernel; the first version of this file divided the
+// median wave lifetime by the instruction count and reported 0.7 "cycles" for v_add)
 // Each wave runs 8 independent dependency chains; a 256-thread block places one wave on each SIMD of a CU, and
 // `w` blocks per CU give w waves per SIMD.  Everything stays in registers (the LDS variant reads one broadcast dword).
 // Run it under `rocprofv3 --pmc GRBM_GUI_ACTIVE` as well: GRBM_GUI_ACTIVE / 8 / duration is the same clock seen from outside.
@@ -106,8 +109,9 @@ int run(const char* name, unsigned long long* d_st, float* d_out, int n_cu, int 
     std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
     const double n_inst = (double)iters * 64;
     const double med_cyc = cyc[cyc.size() / 2], med_clk = clk.empty() ? 0.0 : clk[clk.size() / 2];
-    printf("%-30s waves/SIMD %d  %6.2f cycles per wave-instr per SIMD  clock %.2f GHz  (wall %.3f ns per instr per SIMD)%s\n",
-           name, w, med_cyc / (w * n_inst), med_clk, ms * 1e6 / (n_inst * w), note);
+    const double wall_ns = ms * 1e6 / (n_inst * w);
+    printf("%-30s waves/SIMD %d  %6.2f cycles per wave-instr per SIMD  clock %.2f GHz  (wall %.3f ns per instr per SIMD; a wave is resident %.0f %% of the kernel)%s\n",
+           name, w, wall_ns * med_clk, med_clk, wall_ns, 100.0 * med_cyc / (ms * 1e6 * med_clk), note);
     return 0;
 }
 
