@@ -423,8 +423,8 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
 
 // The material walk of a tagged program (rm_interp.h map_scene_material) as straight-line code: one evaluation of the
 // program WITH its Material tags at the position of a hit, every value a (distance, index) pair of named variables --
-// no stack in LDS, no decode.  Distances go through the operations map_scene_material applies (generic sqrt, the
-// interpreter's leaf functions and operators), indices through its selection rules: primitives carry 0, a tag overwrites
+// no stack in LDS, no decode.  Distances go through the operations map_scene_material applies (the interpreter's leaf
+// functions and operators; the short exact sqrt with its guard, the generic one when the guard objects), indices through its selection rules: primitives carry 0, a tag overwrites
 // the index of the value on top, an operator keeps the index of the operand that decides its result (Union / SmoothUnion
 // b < a, Subtraction -b > a, Intersection b > a take b's; ties and NaN a's).  Parameters -- tag indices included -- are
 // read from the device copy of the tagged records (uniform addresses: scalar loads), so they stay data.
@@ -432,12 +432,12 @@ inline bool generate_material_walk(const std::vector<RmRecord>& mrec, std::strin
     std::string s;
     char line[768];
     s += "namespace rmk {\n";
-    s += "RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz) {\n";
-    s += "    SqrtGuard unused;\n";
+    s += "template <bool FAST>\n";
+    s += "RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz, SqrtGuard& tiny) {\n";
     s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
     std::vector<int> stack, pos;
     pos.push_back(0);
-    int nv = 0, np = 0;
+    int nv = 0, np = 0, leaves = 0;
     for (size_t i = 0; i < mrec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(mrec[i].op), mode = RM_OP_MODE(mrec[i].op);
         const unsigned r = (unsigned)i;
@@ -504,15 +504,17 @@ inline bool generate_material_walk(const std::vector<RmRecord>& mrec, std::strin
             stack.push_back(w);
             continue;
         }
-        const char* fn = kind == RM_KIND_SPHERE ? "sdf_sphere_t<false>" : kind == RM_KIND_BOX ? "sdf_box_t<false>"
-                       : kind == RM_KIND_CYLINDER ? "sdf_cylinder_t<false>" : nullptr;
+        const char* fn = kind == RM_KIND_SPHERE ? "sdf_sphere_t<FAST>" : kind == RM_KIND_BOX ? "sdf_box_t<FAST>"
+                       : kind == RM_KIND_CYLINDER ? "sdf_cylinder_t<FAST>" : nullptr;
         const int c = pos.back();
         const int leaf = nv++;  // the leaf's own value; its index is 0
-        if (fn) std::snprintf(line, sizeof line, "    const float v%d = %s(x%d, y%d, z%d, mp[%u].p, unused);\n", leaf, fn, c, c, c, r);
+        if (fn) std::snprintf(line, sizeof line, "    const float v%d = %s(x%d, y%d, z%d, mp[%u].p, tiny);\n", leaf, fn, c, c, c, r);
         else if (kind == RM_KIND_PLANE)
             std::snprintf(line, sizeof line, "    const float v%d = ((x%d * mp[%u].p[0] + y%d * mp[%u].p[1]) + z%d * mp[%u].p[2]) + mp[%u].p[3];\n", leaf, c, r, c, r, c, r, r);
         else return false;
         s += line;
+        if (fn) s += "    guard_fence(tiny);\n";
+        if (++leaves % 2 == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";  // as in map_scene_spec: bounds the compiler's hoisting
         if (mode == RM_MODE_PUSH) {
             std::snprintf(line, sizeof line, "    const uint32_t m%d = 0u;\n", leaf);
             s += line;

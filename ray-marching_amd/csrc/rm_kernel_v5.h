@@ -54,7 +54,8 @@ RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, un
 #ifdef RM_JIT_MATERIAL_WALK
 // The material walk of a tagged program as straight-line code (rm_jit.h generate_material_walk): which material does the
 // surface at (x, y, z) carry.  mp: the tagged records in device memory (uniform addresses: scalar loads).
-RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz);
+template <bool FAST>
+RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float qx, float qy, float qz, SqrtGuard& tiny);
 #endif
 #ifdef RM_JIT_TAPS4
 // The four normal taps of a hit at c in one pass (rm_jit.h generate_map_scene_taps): f[t] = map_scene(c + k_t eps).
@@ -556,7 +557,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 const uint32_t e = hq_n + lane;
                 const float hx = hq_v[e], hy = hq_v[V5_HQ + e], hz = hq_v[2u * V5_HQ + e];
 #ifdef RM_JIT_MATERIAL_WALK
-                const uint32_t m = map_scene_material_spec(L.mprog, hx, hy, hz);
+                SqrtGuard mtiny;
+                uint32_t m = map_scene_material_spec<true>(L.mprog, hx, hy, hz, mtiny);
+                if (mtiny.any_bad()) m = map_scene_material_spec<false>(L.mprog, hx, hy, hz, mtiny);
 #else
                 const uint32_t m = map_scene_material(L.mprog, L.n_mrec, spill, L.mat_value_depth, hx, hy, hz);
 #endif

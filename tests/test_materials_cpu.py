@@ -125,14 +125,14 @@ def test_generated_kernel_of_a_tagged_program():
     # the distance code (march function and four-tap function) is the untagged scene's, text for text ...
     def body(s):
         end = s.index("RM_DEV uint32_t map_scene_material_spec") if "map_scene_material_spec(const" in s else s.index('extern "C"')
-        return s[s.index("map_scene_spec"):end].replace("namespace rmk {\n", "").rstrip()
+        return s[s.index("map_scene_spec"):end].replace("namespace rmk {\n", "").replace("template <bool FAST>\n", "").rstrip()
     tagged_src = renderer.jit_source(cct, wt)
     assert body(tagged_src) == body(renderer.jit_source(cc8, w8))
     # ... and the material walk follows it as straight-line code: (distance, index) pairs, the tag read as data
     assert "#define RM_JIT_MATERIAL_WALK 1" in tagged_src
     walk = tagged_src[tagged_src.index("RM_DEV uint32_t map_scene_material_spec"):tagged_src.index('extern "C"')]
     lines = [l.strip() for l in walk.splitlines()]
-    assert "const float v1 = vmin(v0, sdf_box_t<false>(x0, y0, z0, mp[1].p, unused)); const uint32_t m1 = v1 < v0 ? 0u : m0;" not in lines
+    assert "const float v1 = vmin(v0, sdf_box_t<FAST>(x0, y0, z0, mp[1].p, tiny)); const uint32_t m1 = v1 < v0 ? 0u : m0;" not in lines
     assert "const float v2 = vmin(v0, v1); const uint32_t m2 = v1 < v0 ? 0u : m0;" in lines        # (S u B): the box decides -> index 0
     assert "const float v4 = vmax_negb(v2, v3); const uint32_t m4 = -v3 > v2 ? 0u : m2;" in lines  # ... - S
     assert any(l.startswith("const float v7 = v6; const uint32_t m7 = __float_as_uint(mp[4].p[0]);") for l in lines)   # the root's tag
