@@ -441,7 +441,7 @@ def valu_view(args, res, march_ms, evals, words):
     """The honest bound: FP32 vector issue.  Instruction counts and the clock come from the committed PMC
     pass of this configuration (profiles/pmc_traffic.json), the duration from this run (march kernel, one frame in
     flight).  Floor: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md), transcendental
-    ones for 4 (profiles/r02_ubench_valu_issue_cycles.txt)."""
+    ones for 8 (profiles/r02_ubench_valu_issue_cycles.txt)."""
     from ray_marching_amd import _ffi
     out = {}
     # algorithmic flops of the reference's map_scene for this program (SURVEY 8(d): 10 / sphere, 22 / box, 1 / union,
@@ -466,7 +466,10 @@ def valu_view(args, res, march_ms, evals, words):
         clock_ghz = pmc.get("clock_ghz", 2.4)
         flop_insts = pmc["SQ_INSTS_VALU_ADD_F32"] + pmc["SQ_INSTS_VALU_MUL_F32"] + 2.0 * pmc["SQ_INSTS_VALU_FMA_F32"] + trans
         cycles_per_inst = march_ms * 1e-3 * clock_ghz * 1e9 * simds / insts
-        floor_cycles = (VALU_CYCLES_PER_WAVE_INST * (insts - trans) + pmc.get("trans_issue_cycles", 4.0) * trans) / insts
+        t_cyc = pmc.get("trans_issue_cycles", 8.0)
+        floor_cycles = (VALU_CYCLES_PER_WAVE_INST * (insts - trans) + t_cyc * trans) / insts
+        meas = pmc.get("measured_simple_issue_cycles")
+        meas_floor = (meas * (insts - trans) + t_cyc * trans) / insts if meas else None
         out.update({
             "bound": "fp32 valu issue",
             "valu_insts_per_frame": insts,
@@ -474,11 +477,16 @@ def valu_view(args, res, march_ms, evals, words):
             "cycles_per_valu_inst_per_simd": cycles_per_inst,
             "issue_floor_cycles_per_inst": floor_cycles,
             "frac_of_valu_issue": floor_cycles / cycles_per_inst,
+            "measured_issue_cycles_per_inst": meas_floor,
+            "frac_of_measured_valu_issue": meas_floor / cycles_per_inst if meas_floor else None,
+            "lds_pipe_busy": pmc.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (simds / 4.0) / (march_ms * 1e-3 * clock_ghz * 1e9) if pmc.get("SQ_ACTIVE_INST_LDS") else None,
             "executed_fp32_TFLOPs": flop_insts * 64.0 * pmc["lane_occupancy"] / (march_ms * 1e-3) / 1e12,
             "peak_fp32_vector_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
-            "valu_note": "instruction counts and clock: committed rocprofv3 PMC pass of this configuration (" + pmc.get("source", "profiles/") +
-                         "); floor: 2 cycles per wave64 VALU instruction on a SIMD-32, transcendentals more; the 157.3 TFLOP/s peak "
-                         "assumes packed FMAs, the arithmetic contract forbids fusing (DESIGN 2)",
+            "valu_note": "instruction counts and clock (GRBM_GUI_ACTIVE / 8 / duration): committed rocprofv3 PMC pass of this configuration (" +
+                         pmc.get("source", "profiles/") + "); floor: 2 cycles per wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md), "
+                         "transcendentals 8; `measured`: what back-to-back v_add / v_mul / v_fma reach on this chip, 2.3-2.4 cycles "
+                         "(profiles/r02_ubench_valu_issue_cycles.txt); lds_pipe_busy = SQ_ACTIVE_INST_LDS (quad-cycles) per CU over the kernel's "
+                         "cycles; the 157.3 TFLOP/s peak assumes packed FMAs, the arithmetic contract forbids fusing (DESIGN 2)",
         })
     return out
 
