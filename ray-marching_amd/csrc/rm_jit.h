@@ -129,7 +129,9 @@ inline int jit_knob(const char* name, int dflt) {
 }
 
 inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
-    const bool count = prune && std::getenv("RM_JIT_PRUNE_STATS") != nullptr;  // diagnostics: count evaluated leaves
+    // diagnostics (tools/wave_stats.py): 1 counts evaluated leaves, 2 leaf tests executed (leaves of near groups), 3 near groups
+    const int count_mode = prune ? jit_knob("RM_JIT_PRUNE_STATS", 0) : 0;
+    const bool count = count_mode == 1;
     std::string s;
     char line[512];
     s += "namespace rmk {\n";
@@ -160,6 +162,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
         const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u;
         std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, x0, y0, z0, thrk);\n", g, goff);
         s += line;
+        if (count_mode == 3) { std::snprintf(line, sizeof line, "    if (g%d) n_eval += 1u;\n", g); s += line; }
     }
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
@@ -227,11 +230,12 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
                 std::snprintf(line, sizeof line, "    if (g%d)\n", grp);
                 s += line;
             }
+            const char* tested = count_mode == 2 ? "n_eval += 1u; " : "";
             if (kind == RM_KIND_SPHERE) {
-                std::snprintf(line, sizeof line, "    { const float a = spec_sphere_a(lp + %u, %s);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", off, P, off);
+                std::snprintf(line, sizeof line, "    { %sconst float a = spec_sphere_a(lp + %u, %s);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", tested, off, P, off);
                 std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
             } else {
-                std::snprintf(line, sizeof line, "    { const SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_any_near(live, b.a > thr2k)) ", off, P);
+                std::snprintf(line, sizeof line, "    { %sconst SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_any_near(live, b.a > thr2k)) ", tested, off, P);
                 std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
             }
             s += line;

@@ -782,7 +782,7 @@ RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const 
     float cx = 0.0f, cy = 0.0f, cz = 0.0f, ex[4], ey[4], ez[4];
 #pragma unroll
     for (uint32_t c = 0; c < 4u; c++) {
-        gen_ray(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex[c], ey[c], ez[c]);
+        gen_ray_unnormalized(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex[c], ey[c], ez[c]);  // unit_dir normalises
         unit_dir(ex[c], ey[c], ez[c]);
         cx += ex[c]; cy += ey[c]; cz += ez[c];
     }

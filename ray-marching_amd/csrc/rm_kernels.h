@@ -64,6 +64,19 @@ RM_DEV void gen_ray(const rm_uniforms& u, const V4& ro, float sx, float sy, uint
     dz = ez / len;
 }
 
+// The same ray up to a positive factor, for the miss tests only (they normalise with unit_dir themselves): pt_world - ro_world
+// without wgsl:62's vec4 normalize -- no sqrt, no three correctly rounded divisions.  NOT a value of the arithmetic contract.
+RM_DEV void gen_ray_unnormalized(const rm_uniforms& u, const V4& ro, float sx, float sy, uint32_t i, uint32_t j,
+                                 float& ex, float& ey, float& ez) {
+    float rx = ((float)i + 0.5f) / 4.0f - 0.5f;
+    float ry = ((float)j + 0.5f) / 4.0f - 0.5f;
+    float ox = rx / u.viewport_extent[0] * 2.0f;
+    float oy = ry / u.viewport_extent[1] * 2.0f;
+    V4 pv = matvec(u.inv_proj, sx + ox, sy + oy, -1.0f, 1.0f);
+    V4 pw = matvec(u.inv_view, pv.x, pv.y, pv.z, pv.w);
+    ex = pw.x - ro.x; ey = pw.y - ro.y; ez = pw.z - ro.z;
+}
+
 // Diffuse intensity of a hit (wgsl:98-103) from the un-normalised tetrahedron sum n.
 RM_DEV float shade_hit(float nx, float ny, float nz, float px, float py, float pz) {
     float nl = __builtin_sqrtf((nx * nx + ny * ny) + nz * nz);

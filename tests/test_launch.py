@@ -1,11 +1,14 @@
 """The rank launcher behind `bench.py --gpus N` (ray-marching_amd/launch.py): one fresh process per rank with the
-environment torch.distributed.run would set, rank 0's stdout captured, failures propagated.  CPU only (gloo)."""
+environment torch.distributed.run would set, rank 0's stdout captured, failures propagated.  CPU (gloo); the two tests
+marked gpu run bench.py itself, as one command, at N = 1 and with two ranks sharing one GPU."""
 import json
 import os
 import subprocess
 import sys
 import textwrap
 import time
+
+import pytest
 
 from ray_marching_amd import launch
 
@@ -92,3 +95,42 @@ def test_bench_mode_defaults():
     a = bench.parse(["--gpus", "8"])
     assert a.mode == "auto" and a.camera == "still" and a.frames_in_flight == 4
     assert bench.parse([]).gpus == 1
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_tile_one_frame_and_gather_it():
+    """`bench.py --gpus 2` as ONE command on a one-GPU box (both ranks on GPU 0, gloo for the timing barrier): the
+    north-star layout -- frame tiled over the ranks in interleaved strips, host-side gather into one shared-memory frame --
+    end to end, and the gathered frame is the single-GPU frame byte for byte."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--all-ranks-on-device0", "--dist-backend", "gloo",
+                        "--steps", "6", "--warmup", "2", "--width", "640", "--height", "360"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["steps"] == 6 and line["value"] > 0
+    assert "interleaved 16-row strips" in line["config"]["sharding"] and line["config"]["specialized_kernel"] is True
+    assert line["end_to_end"]["gathered_frame_identical_to_one_gpu_render"] is True
+    assert line["end_to_end"]["value"] > 0 and line["frames_sharded"]["scaling"] == "weak"
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel_ms"] > 0
+    assert line["vs_baseline"] is None and line["unit"] == "Mpixels/s"
+
+
+@pytest.mark.gpu
+def test_bench_one_gpu_line_has_every_contract_key():
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-sample-div", "8"],
+                       capture_output=True, text=True, timeout=600,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["scaling"] is None and line["dtype"] == "f32" and line["data"] == "synthetic"
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert key in line["roofline"], key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert key in line["cpu_baseline"], key
+    assert line["cpu_baseline"]["kind"] == "port"
+    assert line["one_frame_in_flight"]["kernel_ms"] <= line["one_frame_in_flight"]["draw_ms"]
+    assert line["ab_interpreter_kernel"]["same_image"] is True and line["end_to_end"]["gathered_frame_identical_to_one_gpu_render"] is True

@@ -58,7 +58,10 @@ print("iterations: mean %.1f p50 %d p90 %d p99 %d max %d ; sum %d" %
       (iters.mean(), np.percentile(iters, 50), np.percentile(iters, 90), np.percentile(iters, 99), iters.max(), iters.sum()))
 print("lane occupancy over iterations: %.3f ; refills/wave %.1f" % (live.sum() / max(1, iters.sum() * 64), refills.mean()))
 if a.prune and os.environ.get("RM_JIT_PRUNE_STATS"):
-    print("leaves evaluated / (iterations x leaves): %.3f" % (refills.sum() / max(1.0, float(iters.sum()) * a.leaves)))
+    what = {"1": "leaves evaluated", "2": "leaf tests executed (leaves of near groups)", "3": "near groups"}.get(os.environ["RM_JIT_PRUNE_STATS"], "?")
+    per = a.leaves if os.environ["RM_JIT_PRUNE_STATS"] != "3" else a.leaves // 2
+    print("%s: %.2f per iteration = %.3f of %d (iterations include tap phases, which are not counted)" % (
+        what, refills.sum() / max(1.0, float(iters.sum())), refills.sum() / max(1.0, float(iters.sum()) * per), per))
 k = np.argsort(-end)[:8]
 for i in k:
     print("  late wave: slot %d tile %d start %.0f end %.0f dur %.0f iters %d live/iter %.1f" %
