@@ -321,6 +321,15 @@ def run_rank(args):
                 for k in range(max(0, K - (D - 1)), K):
                     deliver(k)
 
+            # set-up, not a step: the first copy into each slot of the freshly registered frame pays a one-off mapping cost
+            # (~6 ms per slot at 1080p)
+            for i in range(D):
+                prepare(ctxs[i], unis[0])
+                (draw_strips if world > 1 else draw_full)(i)
+                if my_rows:
+                    ctxs[i].gather_strips(W, H, SR, rank, world, strips[i].data_ptr(), shared.slot_address(i), stream=streams[i].cuda_stream)
+            torch.cuda.synchronize()
+            host_barrier()
             e_el, _, _ = timed(D, draw_strips if world > 1 else draw_full, unis, after_issue, finish)
             state["base"] += K
             host_barrier()

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -819,6 +820,25 @@ RM_EXPORT int rm_gather_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip
     uint8_t* dst = static_cast<uint8_t*>(host_image);
     if (stride == 1u) {  // one GPU: the compact buffer IS the frame
         HIP_TRY(c, hipMemcpyAsync(dst, src, row_bytes * H, hipMemcpyDeviceToHost, s));
+        return RM_OK;
+    }
+    // This GPU's strips are equally spaced in the frame: all the full ones go in ONE pitched copy (a row of the copy = one
+    // strip, destination pitch = `stride` strips), a ragged last strip in a second one.  RM_GATHER_PER_STRIP=1: one copy per
+    // strip (A/B).
+    static const bool per_strip = std::getenv("RM_GATHER_PER_STRIP") != nullptr;
+    const size_t strip_bytes = row_bytes * strip_rows;
+    uint32_t n_mine = 0, n_full = 0;
+    for (uint32_t sidx = first; sidx < n_strips; sidx += stride) {
+        n_mine++;
+        if ((sidx + 1u) * strip_rows <= H) n_full++;
+    }
+    if (!per_strip && n_full >= 2u) {
+        HIP_TRY(c, hipMemcpy2DAsync(dst + strip_bytes * first, strip_bytes * stride, src, strip_bytes, strip_bytes, n_full,
+                                    hipMemcpyDeviceToHost, s));
+        if (n_mine > n_full) {  // the frame's last strip is this GPU's and is shorter
+            const uint32_t sidx = first + n_full * stride, r0 = sidx * strip_rows;
+            HIP_TRY(c, hipMemcpyAsync(dst + row_bytes * r0, src + strip_bytes * n_full, row_bytes * (H - r0), hipMemcpyDeviceToHost, s));
+        }
         return RM_OK;
     }
     for (uint32_t sidx = first; sidx < n_strips; sidx += stride) {
