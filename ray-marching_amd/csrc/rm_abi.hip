@@ -550,6 +550,14 @@ hipStream_t user_stream(const rm_ctx* c, void* stream) {
 // draws have not run and cannot race), makes the record fail: there is nothing to wait for then.
 void order_with_previous(rm_ctx* c, hipStream_t s) {
     if (c->last_stream_valid && c->last_stream != s) {
+        // a stream that is being captured cannot wait for work outside its graph (the attempt would invalidate the capture):
+        // capture a draw on the stream the context drew on last
+        hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &capturing) != hipSuccess) (void)hipGetLastError();
+        if (capturing != hipStreamCaptureStatusNone) {
+            c->last_stream = s;
+            return;
+        }
         if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
             if (hipStreamWaitEvent(s, c->ev_order, 0) != hipSuccess) (void)hipGetLastError();
         } else {

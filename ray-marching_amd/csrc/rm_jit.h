@@ -129,7 +129,8 @@ inline int jit_knob(const char* name, int dflt) {
 }
 
 inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
-    // diagnostics (tools/wave_stats.py): 1 counts evaluated leaves, 2 leaf tests executed (leaves of near groups), 3 near groups
+    // diagnostics (tools/wave_stats.py): 1 counts evaluated leaves, 2 leaf tests executed (leaves of near groups), 3 near groups,
+    // 4 (group, lane) pairs that are near
     const int count_mode = prune ? jit_knob("RM_JIT_PRUNE_STATS", 0) : 0;
     const bool count = count_mode == 1;
     std::string s;
@@ -163,6 +164,10 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
         std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, x0, y0, z0, thrk);\n", g, goff);
         s += line;
         if (count_mode == 3) { std::snprintf(line, sizeof line, "    if (g%d) n_eval += 1u;\n", g); s += line; }
+        if (count_mode == 4) {  // lanes for which the group is near (what a perfectly coherent wave would pay for)
+            std::snprintf(line, sizeof line, "    n_eval += spec_group_near_lanes(live, lp + %u, x0, y0, z0, thrk);\n", goff);
+            s += line;
+        }
     }
     for (size_t i = 0; i < rec.size(); i++) {
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);

@@ -126,6 +126,13 @@ RM_DEV bool spec_group_near(unsigned long long live, LdsF r, float qx, float qy,
     const float t = thrk + p.w;
     return spec_any_near(live, a > t * t);
 }
+RM_DEV uint32_t spec_group_near_lanes(unsigned long long live, LdsF r, float qx, float qy, float qz, float thrk) {  // diagnostics
+    const lds_f4 p = lds_load4(r);
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float t = thrk + p.w;
+    return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!(a > t * t)) & live);
+}
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
     const lds_f4 c = lds_load4(r);       // cx cy cz rx

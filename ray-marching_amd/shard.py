@@ -92,7 +92,13 @@ class SharedImage:
         self._image_bytes = (nbytes + 4095) // 4096 * 4096
         total = self._image_bytes + 8 * max(world, 1)
         if rank == dst:
-            self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=total)
+            try:
+                self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=total)
+            except FileExistsError:      # left behind by a run that died: the name is ours (it carries our launcher's pid)
+                stale = shared_memory.SharedMemory(name=self.name)
+                stale.close()
+                stale.unlink()
+                self._shm = shared_memory.SharedMemory(name=self.name, create=True, size=total)
             np.ndarray((max(world, 1),), dtype=np.int64, buffer=self._shm.buf, offset=self._image_bytes)[:] = 0
         if world > 1:
             barrier()

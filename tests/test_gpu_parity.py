@@ -1003,5 +1003,23 @@ def test_gather_strips_reassembles_the_frame_on_the_host(oracle):
             assert_same(pageable, ref)
         with pytest.raises(_ffi.RmError):
             r.gather_strips(W, H, 8, 0, 1, 1, 1)          # strip_rows must be a multiple of 16
+        # BASELINE config 4's row width (7680 px = 1.97 MB per strip, destination pitch 15.7 MB for 8 GPUs): the pitched copy
+        # of every rank's strips against the frame one GPU renders
+        W2, H2 = 7680, 272                                # 17 strips: rank 0 of 8 owns three, the last of them ...
+        cc8, w8, u8 = oracle_case(oracle, scenes.g8(), W2, H2, None)
+        r.set_limits((0.01, 100.0, 48))
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u8)))
+        r.set_program(cc8, w8)
+        whole = r.draw(W2, H2)
+        for world, H3 in ((8, H2), (8, H2 - 8)):         # ... full, then ragged (8 rows)
+            full3 = whole if H3 == H2 else r.draw(W2, H3)
+            pinned = torch.zeros((H3, W2, 4), dtype=torch.float32).pin_memory()
+            for rank in range(world):
+                rows = shard.strip_row_count(H3, 16, rank, world)
+                buf = torch.zeros((max(rows, 1), W2, 4), dtype=torch.float32, device="cuda")
+                assert r.draw_strips_device(W2, H3, 16, rank, world, buf.data_ptr(), stream=s.cuda_stream) == rows
+                r.gather_strips(W2, H3, 16, rank, world, buf.data_ptr(), pinned.data_ptr(), stream=s.cuda_stream)
+                s.synchronize()
+            assert_same(pinned.numpy(), full3)
     finally:
         r.close()

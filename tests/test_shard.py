@@ -89,3 +89,34 @@ def test_two_rank_gloo_tiled_render_matches_single():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert ok and frames == [0, 2, 4]
+
+
+def test_shared_image_slots_counters_and_stale_segment():
+    """The shared frame of the multi-GPU gather: frame slots, one completion counter per rank, and a segment left behind
+    by a run that died is replaced instead of failing the next run."""
+    import os
+    import threading
+    import time
+    from multiprocessing import shared_memory
+    name = "rm_test_shared_%d" % os.getpid()
+    stale = shared_memory.SharedMemory(name=name, create=True, size=64)      # what a crashed run leaves in /dev/shm
+    stale.close()
+    img = shard.SharedImage(name, 8, 6, slots=2).open(0, 1, lambda: None)
+    try:
+        assert img.images.shape == (2, 6, 8, 4) and img.slot(3) is not None and img.slot_address(1) - img.slot_address(0) == 6 * 8 * 16
+        assert img.flags.shape == (1,) and int(img.flags[0]) == 0
+        img.slot(1)[:] = 7.0
+        assert float(img.images[1].min()) == 7.0 and float(img.images[0].max()) == 0.0
+        img.mark_done(0, 3)
+        img.wait_all(3)                                                        # returns at once
+        t = threading.Timer(0.2, lambda: img.mark_done(0, 4))
+        t.start()
+        t0 = time.monotonic()
+        img.wait_all(4, timeout=10.0)                                          # waits for the counter
+        assert 0.1 < time.monotonic() - t0 < 5.0
+        with pytest.raises(TimeoutError):
+            img.wait_all(5, timeout=0.2)
+    finally:
+        img.close()
+    with pytest.raises(FileNotFoundError):
+        shared_memory.SharedMemory(name=name)                                  # the owner unlinked it

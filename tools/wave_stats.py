@@ -58,8 +58,12 @@ print("iterations: mean %.1f p50 %d p90 %d p99 %d max %d ; sum %d" %
       (iters.mean(), np.percentile(iters, 50), np.percentile(iters, 90), np.percentile(iters, 99), iters.max(), iters.sum()))
 print("lane occupancy over iterations: %.3f ; refills/wave %.1f" % (live.sum() / max(1, iters.sum() * 64), refills.mean()))
 if a.prune and os.environ.get("RM_JIT_PRUNE_STATS"):
-    what = {"1": "leaves evaluated", "2": "leaf tests executed (leaves of near groups)", "3": "near groups"}.get(os.environ["RM_JIT_PRUNE_STATS"], "?")
-    per = a.leaves if os.environ["RM_JIT_PRUNE_STATS"] != "3" else a.leaves // 2
+    mode = os.environ["RM_JIT_PRUNE_STATS"]
+    what = {"1": "leaves evaluated", "2": "leaf tests executed (leaves of near groups)", "3": "near groups",
+            "4": "(group, live lane) pairs that are near, per 64 lanes"}.get(mode, "?")
+    per = a.leaves if mode in ("1", "2") else a.leaves // 2
+    if mode == "4":
+        refills = refills / 64.0
     print("%s: %.2f per iteration = %.3f of %d (iterations include tap phases, which are not counted)" % (
         what, refills.sum() / max(1.0, float(iters.sum())), refills.sum() / max(1.0, float(iters.sum()) * per), per))
 k = np.argsort(-end)[:8]
