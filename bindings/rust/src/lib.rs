@@ -99,6 +99,7 @@ pub const RM_INFO_SPECIALIZED: c_int = 6;
 pub const RM_INFO_JIT_STATE: c_int = 7;
 pub const RM_INFO_JIT_COMPILE_MS: c_int = 8;
 pub const RM_INFO_PRUNED: c_int = 9;
+pub const RM_INFO_INTERPRETER_LOOP: c_int = 10;
 
 /// `RM_JIT_PRUNE`: OR into `waves_per_tile` of rm_jit_source / rm_jit_compile.
 pub const RM_JIT_PRUNE: c_int = 0x100;

@@ -164,7 +164,10 @@ enum rm_info {
     RM_INFO_JIT_STATE = 7,       /* specialisation of the current program: 0 none requested, 1 compiling, 2 ready, 3 failed
                                     (rm_jit_log has the reason) */
     RM_INFO_JIT_COMPILE_MS = 8,  /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
-    RM_INFO_PRUNED = 9           /* 1 when the kernel requested for the current program is the pruned form (RM_OPT_PRUNE) */
+    RM_INFO_PRUNED = 9,          /* 1 when the kernel requested for the current program is the pruned form (RM_OPT_PRUNE) */
+    RM_INFO_INTERPRETER_LOOP = 10 /* record loop the interpreter kernels ran the program of the last march launch with: 0 the
+                                    general one (value stack, every node type; also reported when a specialised kernel ran), 1 the chain loop ("a op b op c ...": no
+                                    stack), 2 the chain loop with far pairs of primitives skipped (exact; the default for chains) */
 };
 
 int rm_abi_version(void);

@@ -40,7 +40,7 @@ RM_OPT_OUTPUT_FORMAT = 10
 RM_FORMAT_RGBA32F, RM_FORMAT_RGBA8_UNORM, RM_FORMAT_BGRA8_UNORM = 0, 1, 2
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT, RM_INFO_SPECIALIZED, RM_INFO_JIT_STATE, RM_INFO_JIT_COMPILE_MS = 4, 5, 6, 7, 8
-RM_INFO_PRUNED = 9
+RM_INFO_PRUNED, RM_INFO_INTERPRETER_LOOP = 9, 10
 
 _hip = None
 _host = None

@@ -105,6 +105,7 @@ struct rm_ctx {
     int spec_wpt = 0;
     bool spec_pruned = false;
     bool last_specialized = false;  // the last march launch ran a specialised kernel
+    int last_loop = 0;              // RM_INFO_INTERPRETER_LOOP of the last march launch
     // stream-ordered uploads (program records, bounds, batch uniforms): four pinned staging buffers, see upload()
     struct Staging { void* host = nullptr; size_t cap = 0; hipEvent_t done = nullptr; bool pending = false; };
     Staging staging[4];
@@ -347,7 +348,13 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     bool cull = c->cull && L.n_rec <= 256u && !c->decoded.cull_veto;
     if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi_w
     L.n_cull = cull ? L.n_rec : 0u;
-    L.flags = cull ? 1u : 0u;
+    // interpreter kernels: which map_scene loop a chain program takes (RmLaunch::flags).  RM_CHAIN_MODE (diagnostics):
+    // 0 the general record loop, 1 the chain loop, 2 the chain loop with far pairs skipped (default)
+    static const int chain_mode = std::getenv("RM_CHAIN_MODE") ? std::atoi(std::getenv("RM_CHAIN_MODE")) : 2;
+    const bool chain = c->decoded.is_chain && chain_mode > 0;
+    const bool chain_groups = chain && c->decoded.prunable && c->decoded.groups.size() == c->decoded.rec.size() / 2u;
+    L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (chain_groups && chain_mode >= 2 ? 8u : 0u);
+    c->last_loop = (L.flags & 8u) ? 2 : (L.flags & 4u) ? 1 : 0;
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
     if (!cull) L.n_cone = L.n_slab = 0u;
     const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;
@@ -982,6 +989,7 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     case RM_INFO_DEVICE: *out = c->device; return RM_OK;
     case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
     case RM_INFO_SPECIALIZED: *out = c->last_specialized ? 1.0 : 0.0; return RM_OK;
+    case RM_INFO_INTERPRETER_LOOP: *out = c->last_specialized ? 0.0 : (double)c->last_loop; return RM_OK;
     case RM_INFO_PRUNED: *out = c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty && c->spec_pruned ? 1.0 : 0.0; return RM_OK;
     case RM_INFO_JIT_STATE:
     case RM_INFO_JIT_COMPILE_MS: {

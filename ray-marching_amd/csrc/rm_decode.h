@@ -33,6 +33,9 @@ struct RmDecoded {
     // 1-Lipschitz leaf or a min/max operator; scene_scale = 1 + max over primitives of |centre|_1 + |size|_1
     bool prunable = true;
     float scene_scale = 1.0f;
+    // Chain program: record 0 pushes a sphere / box, every later record is a sphere / box fused with a Union / Subtraction
+    // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
+    bool is_chain = false;
     // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
     // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
     // on the structure only -- the generated code is compiled per structure -- the spheres on the parameters:
@@ -284,6 +287,12 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             d.groups.push_back(g);
             first = nullptr;
         }
+    }
+    if (!d.rec.empty()) {
+        const RmRecord& r0 = d.rec[0];
+        d.is_chain = (RM_OP_KIND(r0.op) == RM_KIND_SPHERE || RM_OP_KIND(r0.op) == RM_KIND_BOX) && RM_OP_MODE(r0.op) == RM_MODE_PUSH &&
+                     (r0.op & RM_OP_SPILL) == 0u;
+        for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) != 0u;
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     d.n_words = ptr;

@@ -88,6 +88,11 @@ RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, uns
 // NaN or inf anywhere (parameters, position, thr) makes the comparison false: the primitive is evaluated.
 // Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned.
 constexpr float kPruneAbs = 4.0e-6f;
+// The thresholds are kept (a register per ray, |sd| of a hit in its hit-buffer entry) by the generated kernels compiled
+// with pruning and by the library's interpreter kernels, whose chain loop prunes too (rm_interp.h map_scene_chain_pruned)
+#if defined(RM_JIT_PRUNE_ON) || !defined(RM_JIT_TU)
+#define RM_PRUNE_PLUMBING 1
+#endif
 // "is the leaf near for ANY live lane": the wave mask of the comparison itself (one v_cmp writing a scalar pair),
 // combined with the live mask on the scalar side.  Written as __ballot(live && !far) the predicate is not a comparison
 // any more and the compiler materialises it in a VGPR and compares it back (v_cndmask + v_cmp_ne: two vector
@@ -428,6 +433,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 uint32_t again = 0u;
                 v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, live_mask, tiny, again);
             }
+        } else if (L.flags & 8u) {  // chain program (wave-uniform): the stack-free record loop, far pairs skipped
+            v[0] = map_scene_chain_pruned<true>(prog, L.n_rec, x, y, z, thr, live_mask, tiny);
+            if (tiny.any_bad()) v[0] = map_scene_chain_pruned<false>(prog, L.n_rec, x, y, z, thr, live_mask, tiny);
+        } else if (L.flags & 4u) {  // chain program, every record evaluated
+            v[0] = map_scene_chain<true>(prog, L.n_rec, x, y, z, tiny);
+            if (tiny.any_bad()) v[0] = map_scene_chain<false>(prog, L.n_rec, x, y, z, tiny);
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
             if (tiny.any_bad())  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
@@ -621,7 +632,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
             ez = hq_v[2u * V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgz);
             is_live = lane < tap_n;
-#ifdef RM_JIT_PRUNE_ON
+#ifdef RM_PRUNE_PLUMBING
             // the tap is eps * sqrt(3) away from the hit position, where the scene value was sd_hit ("Pruning")
             thr = __uint_as_float(hq_rid[he] & ~1023u) * 1.00001f + 1.75e-4f +
                   kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
@@ -629,7 +640,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         } else {
             ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
             is_live = mode == M_MARCH;
-            if constexpr (SPEC) thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+            thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
         }
         n_iter++;
         const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
@@ -672,7 +683,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         const unsigned long long go_m = on_m & ~esc_m;
         sc = select_by_mask(sc, sc + sd, go_m);                                                       // wgsl:114
         it = select_by_mask(it, it + 1u, go_m);
-#ifdef RM_JIT_PRUNE_ON  // only pruned kernels read it
+#ifdef RM_PRUNE_PLUMBING  // only pruning kernels read it
         thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
 #endif
         const unsigned long long miss_mask = esc_m | (go_m & __ballot(it >= L.max_iter));             // loop bound, wgsl:90
@@ -680,7 +691,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
             if (hit) {
                 const uint32_t e = hq_n + lane_rank(hit_mask);
-#ifdef RM_JIT_PRUNE_ON
+#ifdef RM_PRUNE_PLUMBING
                 // |sd| of the hit, rounded up to 22 bits, rides in the upper bits of the entry's ray id (< 1024): the
                 // pruning threshold of its normal taps ("Pruning"); a NaN stays a NaN (nothing is skipped then)
                 hq_rid[e] = rid | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);

@@ -3,6 +3,8 @@ kernel must be indistinguishable from the interpreter kernel and the oracle -- b
 machinery around it (cache per structure, background compilation, fallbacks) must behave as documented."""
 import time
 
+import os
+
 import numpy as np
 import pytest
 
@@ -216,18 +218,25 @@ def test_pruning_policy_by_primitive_count(oracle):
         r.close()
 
 
-def test_grouped_far_tests_far_from_the_origin_and_with_distant_partners(oracle):
+@pytest.mark.parametrize("form", ["generated", "interpreter_lds", "interpreter_scalar_cache"])
+def test_grouped_far_tests_far_from_the_origin_and_with_distant_partners(oracle, form):
     """The pruned form tests pairs of consecutive sphere / box leaves against a bounding sphere first (rm_decode.h:
     RmDecoded::groups).  Scenes that stress the bound: everything 1000 units from the origin (the members' own
     evaluation error is then ~1e-4), partners far apart (a huge group sphere), partners that coincide, degenerate radii,
-    an odd number of leaves; and the same kernel after the parameters moved (group spheres follow the upload)."""
+    an odd number of leaves; and the same kernel after the parameters moved (group spheres follow the upload).  The
+    interpreter kernels run the same pair tests in their chain loop (rm_interp.h map_scene_chain_pruned): variants 0-2 are
+    chains, variant 3 (an Intersection in the middle) takes the general loop."""
     rng = np.random.default_rng(77)
     W, H = 64, 40
     lim = (0.01, 100.0, 80)
     r = renderer.RayMarchingResources(0)
     try:
-        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
-        r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        if form == "generated":
+            r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+            r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        else:
+            r.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
+            r.set_option(_ffi.RM_OPT_KERNEL, _ffi.RM_KERNEL_V5_LDS if form == "interpreter_lds" else _ffi.RM_KERNEL_V5)
         r.set_limits(lim)
         r.resize_command_buffer(4096)
         for offset in ((0.0, 0.0, 0.0), (800.0, -300.0, 500.0)):
@@ -253,6 +262,10 @@ def test_grouped_far_tests_far_from_the_origin_and_with_distant_partners(oracle)
                     r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
                     r.set_program(cc, w)
                     assert r.draw(W, H).tobytes() == oracle.render(u, lim, cc, w, W, H, threads=4).tobytes(), (offset, variant, events)
-                    assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 1
+                    if form == "generated":
+                        assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 1
+                    else:
+                        assert r.info(_ffi.RM_INFO_SPECIALIZED) == 0
+                        assert r.info(_ffi.RM_INFO_INTERPRETER_LOOP) == (0 if variant == 3 else 2), variant
     finally:
         r.close()

@@ -44,16 +44,14 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "const bool g1 = spec_group_near(live, lp + 40, x0, y0, z0, thrk);",
         "float v0 = inf;",
         "if (g0)",
-        "{ const float a = spec_sphere_a(lp + 0, x0, y0, z0);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 0, a, thrk))) { v0 = spec_sphere_v<FAST>(lp + 0, a, tiny); } }",
+        "{ v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny); }",     # a sphere of a near pair: no test of its own
         "float v1 = v0;",
         "if (g0)",
         "{ const SpecBox b = spec_box_a(lp + 8, x0, y0, z0);",
         "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
         "if (g1)",
-        "{ const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
-        "if (spec_any_near(live, spec_sphere_far(lp + 16, a, thrk))) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny)); } }",
+        "{ v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 16, x0, y0, z0, tiny)); }",
         "float v3 = v2;",
         "if (g1)",
         "{ const SpecBox b = spec_box_a(lp + 24, x0, y0, z0);",
@@ -103,6 +101,12 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
             tgt, op, acc = m.groups()
             if not (prune_all_far and prune_all_far(pending)):
                 env[tgt] = pending if op is None else ops[op](env[acc], pending)
+            continue
+        m = re.match(r"\{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(sphere|box)<FAST>\(lp \+ (\d+), x0, y0, z0, tiny\)\)?; \}$", line)
+        if m:             # member of a pair without a far test of its own (spheres): evaluated whenever its pair is near
+            tgt, op, acc, kind, off = m.groups()
+            val = sphere(int(off) // 8) if kind == "sphere" else box(int(off) // 8)
+            env[tgt] = val if op is None else ops[op](env[acc], val)
             continue
         m = re.match(r"const float (v\d+) = (\w+)\((v\d+), (v\d+)\);", line)
         if m:
