@@ -220,7 +220,7 @@ int rm_draw(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, f
 
 /* One GPU's share of an image tiled over `stride` GPUs (north-star: "the image tiles across the
  * GPUs of one node with a final host-side gather"): renders the strips first, first+stride,
- * first+2*stride, ... of strip_rows rows each (strip_rows a multiple of 16) in ONE launch.
+ * first+2*stride, ... of strip_rows rows each (strip_rows a multiple of 8: the kernels work on 8x8-pixel tiles) in ONE launch.
  * out_rgba receives them back to back; *out_rows = number of rows written (0 if this GPU has no
  * strip).  Interleaving balances the load: the costly part of a frame is usually its centre. */
 int rm_draw_strips(rm_ctx* ctx, uint32_t W, uint32_t H, uint32_t strip_rows, uint32_t first, uint32_t stride,

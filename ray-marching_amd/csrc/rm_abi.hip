@@ -788,8 +788,8 @@ RM_EXPORT int rm_draw_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip_r
     if (!out_rows) return fail(c, RM_ERR_NULL, "rm_draw_strips: out_rows is NULL");
     int rc = check_dims(c, W, H, 0, H);
     if (rc != RM_OK) return rc;
-    if (strip_rows == 0u || (strip_rows % 16u) != 0u || stride == 0u || first >= stride)
-        return fail(c, RM_ERR_ARG, "rm_draw_strips: strip_rows %u must be a positive multiple of 16, first %u < stride %u",
+    if (strip_rows == 0u || (strip_rows % 8u) != 0u || stride == 0u || first >= stride)
+        return fail(c, RM_ERR_ARG, "rm_draw_strips: strip_rows %u must be a positive multiple of 8, first %u < stride %u",
                     strip_rows, first, stride);
     const uint32_t rows = strip_row_count(H, strip_rows, first, stride);
     *out_rows = rows;
@@ -822,8 +822,8 @@ RM_EXPORT int rm_gather_strips(rm_ctx* c, uint32_t W, uint32_t H, uint32_t strip
     if (!c) return RM_ERR_NULL;
     int rc = check_dims(c, W, H, 0, H);
     if (rc != RM_OK) return rc;
-    if (strip_rows == 0u || (strip_rows % 16u) != 0u || stride == 0u || first >= stride)
-        return fail(c, RM_ERR_ARG, "rm_gather_strips: strip_rows %u must be a positive multiple of 16, first %u < stride %u",
+    if (strip_rows == 0u || (strip_rows % 8u) != 0u || stride == 0u || first >= stride)
+        return fail(c, RM_ERR_ARG, "rm_gather_strips: strip_rows %u must be a positive multiple of 8, first %u < stride %u",
                     strip_rows, first, stride);
     const uint32_t n_strips = (H + strip_rows - 1u) / strip_rows;
     if (first >= n_strips) return RM_OK;  // this GPU has no strip

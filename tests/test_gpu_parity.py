@@ -293,15 +293,15 @@ def test_interleaved_strips_reassemble_to_the_frame(res, oracle, kernel):
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
     full = res.draw(W, H)
     assert_same(full, oracle.render(u, lim, cc, w, W, H, threads=4))
-    for world in (1, 2, 3, 8):
+    for world, sr in ((1, 16), (2, 16), (3, 16), (8, 16), (2, 8), (5, 8), (8, 8), (3, 24)):
         img = np.zeros_like(full)
         for rank in range(world):
-            compact = res.draw_strips(W, H, 16, rank, world)
-            assert compact.shape[0] == shard.strip_row_count(H, 16, rank, world)
-            shard.scatter_strips(img, compact, H, rank, world, 16)
-        assert img.tobytes() == full.tobytes()
+            compact = res.draw_strips(W, H, sr, rank, world)
+            assert compact.shape[0] == shard.strip_row_count(H, sr, rank, world)
+            shard.scatter_strips(img, compact, H, rank, world, sr)
+        assert img.tobytes() == full.tobytes(), (world, sr)
     with pytest.raises(_ffi.RmError):
-        res.draw_strips(W, H, 12, 0, 2)          # strip height must be a multiple of 16
+        res.draw_strips(W, H, 12, 0, 2)          # strip height must be a multiple of 8 (the kernels' tile height)
     assert res.draw_strips(W, H, 32, 7, 8).shape[0] == 0   # more ranks than strips: empty share
 
 
@@ -989,20 +989,20 @@ def test_gather_strips_reassembles_the_frame_on_the_host(oracle):
         r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
         r.set_program(cc, w)
         s = torch.cuda.Stream()
-        for world in (1, 2, 3, 8):
+        for world, sr in ((1, 16), (2, 16), (3, 16), (8, 16), (3, 8), (8, 8)):
             pinned = torch.zeros((H, W, 4), dtype=torch.float32).pin_memory()
             pageable = np.zeros((H, W, 4), np.float32)
             for rank in range(world):
-                rows = shard.strip_row_count(H, 16, rank, world)
+                rows = shard.strip_row_count(H, sr, rank, world)
                 buf = torch.zeros((max(rows, 1), W, 4), dtype=torch.float32, device="cuda")
-                assert r.draw_strips_device(W, H, 16, rank, world, buf.data_ptr(), stream=s.cuda_stream) == rows
-                r.gather_strips(W, H, 16, rank, world, buf.data_ptr(), pinned.data_ptr(), stream=s.cuda_stream)
-                r.gather_strips(W, H, 16, rank, world, buf.data_ptr(), pageable.ctypes.data, stream=s.cuda_stream)
+                assert r.draw_strips_device(W, H, sr, rank, world, buf.data_ptr(), stream=s.cuda_stream) == rows
+                r.gather_strips(W, H, sr, rank, world, buf.data_ptr(), pinned.data_ptr(), stream=s.cuda_stream)
+                r.gather_strips(W, H, sr, rank, world, buf.data_ptr(), pageable.ctypes.data, stream=s.cuda_stream)
                 s.synchronize()
             assert_same(pinned.numpy(), ref)
             assert_same(pageable, ref)
         with pytest.raises(_ffi.RmError):
-            r.gather_strips(W, H, 8, 0, 1, 1, 1)          # strip_rows must be a multiple of 16
+            r.gather_strips(W, H, 12, 0, 1, 1, 1)         # strip_rows must be a multiple of 8
         # BASELINE config 4's row width (7680 px = 1.97 MB per strip, destination pitch 15.7 MB for 8 GPUs): the pitched copy
         # of every rank's strips against the frame one GPU renders
         W2, H2 = 7680, 272                                # 17 strips: rank 0 of 8 owns three, the last of them ...

@@ -23,7 +23,8 @@
 #define CHK(e) do { hipError_t r_ = (e); if (r_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(r_), __LINE__); return 1; } } while (0)
 
 enum Op { FMA, MUL, ADD, SUB_SGPR, SUB_ABS, MAX, MIN, MAX3, MAX_NEG, CMP_VCC, CMP_SGPR, CNDMASK, RSQ, RCP, SQRT, MOV, ADD_U32, MIN3_U32, XOR,
-          MIX_MAX_ADD, MIX_RSQ_3ADD, MIX_CMP_ADD, LDS_ADD, ADD_LITERAL, N_OPS };
+          MIX_MAX_ADD, MIX_RSQ_3ADD, MIX_CMP_ADD, LDS_ADD, ADD_LITERAL, PK_ADD, PK_MUL, PK_FMA, PK_ADD_BCAST, PK_ADD_NEG, MIX_PK_ADD, MIX_PK_MAX, N_OPS };
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 template <int OP>
 __global__ __launch_bounds__(256) void k(unsigned long long* stamps, float* out, int iters, float seed) {
@@ -33,6 +34,8 @@ __global__ __launch_bounds__(256) void k(unsigned long long* stamps, float* out,
     float a[8];
     for (int i = 0; i < 8; i++) a[i] = seed + threadIdx.x * 0.001f + i;
     float b = seed * 1.0001f, c = seed * 0.5f;
+    f2 a2[8], b2 = {b, c}, c2 = {c, b};  // packed f32 (VOP3P): two values per lane in an even-aligned register pair
+    for (int i = 0; i < 8; i++) a2[i] = f2{seed + threadIdx.x * 0.001f + i, seed - i};
     const float sb = __builtin_amdgcn_readfirstlane(__float_as_uint(b)) ? b : c;  // stays a VGPR; the "s" operand below is forced
     (void)sb;
     const __attribute__((address_space(3))) float* lp = (const __attribute__((address_space(3))) float*)lds;
@@ -68,7 +71,16 @@ __global__ __launch_bounds__(256) void k(unsigned long long* stamps, float* out,
     if (OP == MIX_CMP_ADD) { if ((i & 1) == 0) asm volatile("v_cmp_lt_f32 vcc, %0, %1" : : "v"(a[i]), "v"(b) : "vcc");    \
                              else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }                           \
     if (OP == LDS_ADD) { float p = lp[(i + r) & 63]; asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(p)); }        \
-    if (OP == ADD_LITERAL) asm volatile("v_add_f32 %0, 0x3f8ccccd, %0" : "+v"(a[i]));
+    if (OP == ADD_LITERAL) asm volatile("v_add_f32 %0, 0x3f8ccccd, %0" : "+v"(a[i]));                                      \
+    if (OP == PK_ADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));                                    \
+    if (OP == PK_MUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));                                    \
+    if (OP == PK_FMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a2[i]) : "v"(b2), "v"(c2));                       \
+    if (OP == PK_ADD_BCAST) asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(a2[i]) : "v"(b2));              \
+    if (OP == PK_ADD_NEG) asm volatile("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]" : "+v"(a2[i]) : "v"(b2));      \
+    if (OP == MIX_PK_ADD) { if ((i & 1) == 0) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));            \
+                            else asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }                            \
+    if (OP == MIX_PK_MAX) { if ((i & 1) == 0) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a2[i]) : "v"(b2));            \
+                            else asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b)); }
             REP8(ONE)
 #undef ONE
         }
@@ -76,7 +88,7 @@ __global__ __launch_bounds__(256) void k(unsigned long long* stamps, float* out,
     const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     float s = 0;
-    for (int i = 0; i < 8; i++) s += a[i];
+    for (int i = 0; i < 8; i++) s += a[i] + a2[i].x + a2[i].y;
     out[blockIdx.x * 256 + threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) {
         unsigned long long* st = stamps + 4ull * (blockIdx.x * 4u + (threadIdx.x >> 6));
@@ -125,6 +137,20 @@ int main(int argc, char** argv) {
     CHK(hipMalloc(&d_out, (size_t)n_cu * 8 * 256 * 4));
     printf("# %s, %d CUs; cycles = s_memtime ticks, clock = s_memtime / s_memrealtime (100 MHz); median over waves\n", prop.gcnArchName, n_cu);
     const bool quick = argc > 1 && !strcmp(argv[1], "--quick");
+    if (argc > 1 && !strcmp(argv[1], "--packed")) {  // packed f32 (two values per lane per instruction) next to the plain forms
+        for (int w : {8, 5, 2}) {
+            run<ADD>("v_add_f32", d_st, d_out, n_cu, w);
+            run<FMA>("v_fma_f32", d_st, d_out, n_cu, w);
+            run<PK_ADD>("v_pk_add_f32", d_st, d_out, n_cu, w, "  [two adds per lane]");
+            run<PK_MUL>("v_pk_mul_f32", d_st, d_out, n_cu, w, "  [two multiplies per lane]");
+            run<PK_FMA>("v_pk_fma_f32", d_st, d_out, n_cu, w, "  [two fmas per lane]");
+            run<PK_ADD_BCAST>("v_pk_add_f32 op_sel_hi:[1,0]", d_st, d_out, n_cu, w, "  [second operand: its low half for both]");
+            run<PK_ADD_NEG>("v_pk_add_f32 neg (a - b)", d_st, d_out, n_cu, w);
+            run<MIX_PK_ADD>("mix: v_pk_add, v_add alternating", d_st, d_out, n_cu, w, "  [per instruction of the mix]");
+            run<MIX_PK_MAX>("mix: v_pk_mul, v_max alternating", d_st, d_out, n_cu, w, "  [per instruction of the mix]");
+        }
+        return 0;
+    }
     for (int w : {8, 5, 4, 2, 1}) run<FMA>("v_fma_f32", d_st, d_out, n_cu, w);
     for (int w : {8, 5}) {
         run<ADD>("v_add_f32", d_st, d_out, n_cu, w);
