@@ -368,8 +368,11 @@ def run_rank(args):
             # A/B: the interpreter kernel, i.e. the design north_star spells out (node array staged in LDS and INTERPRETED)
             res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
             a_el, _, a_k = timed(1, draw_full, unis)
+            loop = int(res.info(_ffi.RM_INFO_INTERPRETER_LOOP))
             legs["ab_interpreter_kernel"] = {
-                "kernel": "rm_render_v5 (interpreter: LDS-staged records, accumulator machine), one frame in flight",
+                "kernel": "rm_render_v5 (interpreter: LDS-staged records; %s), one frame in flight"
+                          % ["general record loop, accumulator machine", "stack-free chain loop",
+                             "stack-free chain loop, far pairs of primitives skipped"][min(loop, 2)],
                 "value": W * H * K / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
                 "same_image": float(full[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
             res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)

@@ -110,6 +110,45 @@ def test_deep_stack_programs(res, oracle, kernel):
         assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
 
 
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS], ids=["v5", "v5_lds"])
+def test_interpreter_record_loops(res, oracle, kernel):
+    """Which record loop the interpreter kernels take (RM_INFO_INTERPRETER_LOOP) and that each renders the oracle's image:
+    chains "a op b op c ..." of 1..9 primitives -- the stack-free loop with far pairs skipped (odd lengths leave a last
+    record without a pair, length 1 has no pair at all) -- seen from outside, from inside a primitive and from far away;
+    anything else (a right-deep tree, an operator on two sub-trees, a trailing second value) the general loop."""
+    rng = np.random.default_rng(11)
+    W, H = 56, 40
+    lim = (0.01, 100.0, 96)
+    res.resize_command_buffer(4096)
+    cams = [scenes.STILL_CAMERA_EVENTS, [(2, -30.0, 0.0)] * 4, [(2, 60.0, 0.0), (1, 200.0, 30.0)]]   # Dolly in (among / inside the primitives), far out
+    for n in (1, 2, 3, 4, 5, 8, 9):
+        t = scenes._Tab()
+        leaves = []
+        for k in range(n):
+            c = rng.uniform(-1.5, 1.5, 3)
+            leaves.append(t.sphere(tuple(c), float(rng.uniform(0.3, 0.9))) if rng.random() < 0.5 else
+                          t.box(tuple(c), tuple(rng.uniform(0.2, 0.7, 3))))
+        acc = leaves[0]
+        for k, leaf in enumerate(leaves[1:]):
+            acc = t.op(scenes.SUBTRACTION if k % 3 == 2 else scenes.UNION, acc, leaf)
+        cc, w = oracle.serialize(t.nodes, acc)
+        for events in cams:
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+            assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0 and res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 2, n
+    for scene in (scenes.right_deep(5), scenes.g32_balanced()):
+        cc, w, u = oracle_case(oracle, scene, W, H, None)
+        setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+        assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+        assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
+    # a specialised kernel reports 0 as well (the loop is the interpreter's)
+    cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=KERNEL_SPEC)
+    res.draw(W, H)
+    assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1 and res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
+
+
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)
 def test_program_leaving_two_values_returns_top(res, oracle, kernel):
     # "S S" (no operator): the reference returns the top of stack (wgsl:202)

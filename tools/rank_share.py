@@ -22,6 +22,7 @@ p.add_argument("--steps", type=int, default=200)
 p.add_argument("--frames-in-flight", type=int, default=4)
 p.add_argument("--worlds", default="1,2,4,8")
 p.add_argument("--gather", action="store_true")
+p.add_argument("--waves-per-tile", type=int, default=0)
 p.add_argument("--strip-rows", type=int, default=shard.DEFAULT_STRIP_ROWS)
 a = p.parse_args()
 W, H, K, F = a.width, a.height, a.steps, a.frames_in_flight
@@ -37,6 +38,8 @@ for world in [int(x) for x in a.worlds.split(",")]:
         for _ in range(F):
             r = renderer.RayMarchingResources(0)
             r.set_limits(renderer.RayMarchLimits(0.01, 100.0, a.max_iter))
+            if a.waves_per_tile:
+                r.set_option(_ffi.RM_OPT_WAVES_PER_TILE, a.waves_per_tile)
             r.set_program(cc, words)
             r.set_uniforms(u)
             ctxs.append(r)
@@ -67,7 +70,7 @@ for world in [int(x) for x in a.worlds.split(",")]:
             torch.cuda.synchronize()
             runs.append((time.perf_counter() - t0) / K * 1e3)
         ms = sorted(runs)[len(runs) // 2]
-        print("strips of %d rows, N=%d rank %d: %4d rows  %.3f ms per frame (median of 5 runs, min %.3f)%s -> %6.0f Mpx/s for the job"
-              % (SR, world, rank, rows, ms, min(runs), " incl. D2H of the strips" if a.gather else "", W * H / ms / 1e3), flush=True)
+        print("F=%d wpt=%d strips of %d rows, N=%d rank %d: %4d rows  %.3f ms per frame (median of 5 runs, min %.3f)%s -> %6.0f Mpx/s for the job"
+              % (F, a.waves_per_tile, SR, world, rank, rows, ms, min(runs), " incl. D2H of the strips" if a.gather else "", W * H / ms / 1e3), flush=True)
         for r in ctxs:
             r.close()
