@@ -858,7 +858,9 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     if (L.frames) u = L.frames[blockIdx.z];
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
     const bool tables = (L.flags & 1u) != 0u;
+    __shared__ float s_off[32];  // screen offsets of the 16 AA samples: the same for every pixel, computed once
     if (tid == 0u) *s_veto = 0u;
+    if (tid < 16u) sample_offset(u, tid >> 2, tid & 3u, s_off[2u * tid], s_off[2u * tid + 1u]);
     __syncthreads();
     if (tables)
         for (uint32_t k = tid; k < L.n_rec; k += 64u * V5_PRE_TILES)
@@ -897,19 +899,34 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     const uint32_t pending = (uint32_t)__popcll(__ballot(!clear));
     if (lane == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = pending;  // 0 = finished here
     if (pending != 0u) return;
+    // This loop is most of the pre-pass (60 % of the metric frame's pixels x 16 samples).  Everything that does not depend on
+    // the pixel is taken out of it: the sample offsets (two divisions each) come from the table above, the matrices sit in
+    // vector registers (32 of them; as scalar operands every multiply of the two mat-vecs would issue at half rate), and the
+    // gamma-corrected colour of a sample is one of three values -- black, or the checker colour for bit 0 / 1 (wgsl:127) --
+    // whose square roots are taken once, by the same expressions.
+    float mp[16], mv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mp[k] = u.inv_proj[k]; mv[k] = u.inv_view[k];
+        asm volatile("" : "+v"(mp[k]), "+v"(mv[k]));
+    }
+    float gamma_rg[2], gamma_b[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const float g = 0.2f * (float)c;
+        gamma_rg[c] = __builtin_sqrtf(0.1f + g);
+        gamma_b[c] = __builtin_sqrtf(0.2f + g);
+    }
     float tr = 0.0f, tg = 0.0f, tb = 0.0f;
     for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
         float dx, dy, dz;
-        gen_ray(u, ro, sx, sy, s >> 2, s & 3u, dx, dy, dz);
+        gen_ray_at(mp, mv, ro, sx, sy, s_off[2u * s], s_off[2u * s + 1u], dx, dy, dz);
         const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-        if (c >= 0) {
-            const float g = 0.2f * (float)c;
-            cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
-        }
-        tr += __builtin_sqrtf(cr);
-        tg += __builtin_sqrtf(cg);
-        tb += __builtin_sqrtf(cb);
+        const float rg = c < 0 ? 0.0f : (c ? gamma_rg[1] : gamma_rg[0]);  // sqrt(0) = 0 (wgsl:130)
+        const float b = c < 0 ? 0.0f : (c ? gamma_b[1] : gamma_b[0]);
+        tr += rg;
+        tg += rg;
+        tb += b;
     }
     if (tx < L.W && ty < L.rows) {
         store_pixel(L, blockIdx.z, (size_t)ty * L.W + tx, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75

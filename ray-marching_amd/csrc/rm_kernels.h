@@ -49,19 +49,30 @@ RM_DEV float screen_x(uint32_t px, uint32_t W) { return (((float)px + 0.5f) / (f
 RM_DEV float screen_y(uint32_t py, uint32_t H) { return 1.0f - (((float)py + 0.5f) / (float)H) * 2.0f; }
 
 // Ray direction of AA sample (i,j) through pt_screen (sx,sy): wgsl:52-62.
-RM_DEV void gen_ray(const rm_uniforms& u, const V4& ro, float sx, float sy, uint32_t i, uint32_t j,
-                    float& dx, float& dy, float& dz) {
+// AA sample (i, j) of a pixel: its offset on the screen (wgsl:47-53).  The same 16 pairs for every pixel of a frame.
+RM_DEV void sample_offset(const rm_uniforms& u, uint32_t i, uint32_t j, float& ox, float& oy) {
     float rx = ((float)i + 0.5f) / 4.0f - 0.5f;
     float ry = ((float)j + 0.5f) / 4.0f - 0.5f;
-    float ox = rx / u.viewport_extent[0] * 2.0f;
-    float oy = ry / u.viewport_extent[1] * 2.0f;
-    V4 pv = matvec(u.inv_proj, sx + ox, sy + oy, -1.0f, 1.0f);
-    V4 pw = matvec(u.inv_view, pv.x, pv.y, pv.z, pv.w);
+    ox = rx / u.viewport_extent[0] * 2.0f;
+    oy = ry / u.viewport_extent[1] * 2.0f;
+}
+// The ray through pt_screen + (ox, oy) (wgsl:54-62); m_proj / m_view are the uniform block's matrices (callers may hold
+// them in vector registers: an instruction with a scalar-register operand issues at half rate).
+RM_DEV void gen_ray_at(const float* m_proj, const float* m_view, const V4& ro, float sx, float sy, float ox, float oy,
+                       float& dx, float& dy, float& dz) {
+    V4 pv = matvec(m_proj, sx + ox, sy + oy, -1.0f, 1.0f);
+    V4 pw = matvec(m_view, pv.x, pv.y, pv.z, pv.w);
     float ex = pw.x - ro.x, ey = pw.y - ro.y, ez = pw.z - ro.z, ew = pw.w - ro.w;
     float len = __builtin_sqrtf(((ex * ex + ey * ey) + ez * ez) + ew * ew);
     dx = ex / len;
     dy = ey / len;
     dz = ez / len;
+}
+RM_DEV void gen_ray(const rm_uniforms& u, const V4& ro, float sx, float sy, uint32_t i, uint32_t j,
+                    float& dx, float& dy, float& dz) {
+    float ox, oy;
+    sample_offset(u, i, j, ox, oy);
+    gen_ray_at(u.inv_proj, u.inv_view, ro, sx, sy, ox, oy, dx, dy, dz);
 }
 
 // The same ray up to a positive factor, for the miss tests only (they normalise with unit_dir themselves): pt_world - ro_world
