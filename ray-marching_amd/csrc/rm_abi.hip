@@ -342,6 +342,9 @@ int finish_launch(rm_ctx* c, hipStream_t s);
 int time_begin(rm_ctx* c, hipStream_t s);
 int time_end(rm_ctx* c, hipStream_t s);
 
+// LDS behind the program copy of a march workgroup: {pool cursor, tile slot, veto, pad} + the 16 AA sample offsets (+ pad)
+constexpr size_t kV5TailBytes = 16u + 144u;
+
 template <int WPT>
 int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hipStream_t s) {
     RmLaunch L = L_in;
@@ -367,7 +370,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
     const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
-                         (lds ? (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord) : 0u) + 16u + sizeof(rm_uniforms) +
+                         (lds ? (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord) : 0u) + kV5TailBytes +
                          (L.n_mrec != 0u ? 1024u : 0u);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
@@ -428,7 +431,7 @@ int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStre
     const size_t prog_bytes = (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord);
     const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
     const size_t per_wave = rmk::V5_WAVE_DWORDS * 4u + depth * 256u;
-    const size_t fixed = 4096u + cull_bytes + 16u + sizeof(rm_uniforms) + (L.n_mrec != 0u ? 1024u : 0u);
+    const size_t fixed = 4096u + cull_bytes + kV5TailBytes + (L.n_mrec != 0u ? 1024u : 0u);
     // A long program (rm_resize_command_buffer admits 64 KB of commands, ~2 700 leaves = 85 KB of records) does not fit
     // a workgroup's LDS next to the ray buffers: it is then read through the scalar cache instead (ProgSmem).
     if (lds && fixed + prog_bytes + per_wave > 60u * 1024u) lds = false;

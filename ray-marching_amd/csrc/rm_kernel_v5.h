@@ -392,7 +392,8 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     uint32_t* s_next = lprog + (PROG_IN_LDS ? (L.n_rec + L.n_grp) * 8u : 0u);  // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
     uint32_t* s_veto = s_next + 2;
-    uint8_t* rmat = reinterpret_cast<uint8_t*>(s_next + 4);            // MAT, tagged program: [1024] material per ray
+    float* s_off = reinterpret_cast<float*>(s_next + 4);               // [16][2] screen offsets of the AA samples (wgsl:47-53)
+    uint8_t* rmat = reinterpret_cast<uint8_t*>(s_next + 36);           // MAT, tagged program: [1024] material per ray
     const bool tagged = MAT && L.n_mrec != 0u;                         // wave-uniform
     constexpr uint32_t TAP_IDLE = MAT ? 5u : 4u;                       // tap_t: 0..3 normal taps, 4 (MAT) material, else idle
     const CullTables cullt{t_cone, t_slab, s_veto, L.n_cone, L.n_slab};
@@ -413,6 +414,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         for (uint32_t k = tid; k < (L.n_rec + L.n_grp) * 8u; k += 64u * WPT) lprog[SPEC ? ((k & ~7u) | ((k + 7u) & 7u)) : k] = src[k];
     }
     if (tid == 0u) *s_veto = 0u;
+    if (tid < 16u) sample_offset(u, tid >> 2, tid & 3u, s_off[2u * tid], s_off[2u * tid + 1u]);  // two divisions per sample, once
     __syncthreads();
     if (L.flags & 1u)
         for (uint32_t k = tid; k < L.n_rec; k += 64u * WPT) cull_build_v5(L.prog[k], ro, L.min_dist, L.smooth_slack, t_cone, t_slab, s_veto, L.bounds);
@@ -430,6 +432,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
             v[0] = map_scene_spec<true>(lprog_v, x, y, z, thr, live_mask, tiny, n_eval);
             if (tiny.any_bad()) {
+                // (an empty volatile asm keeps this a branch: for a program of one or two leaves the compiler otherwise
+                // evaluates both forms at every step and selects -- a second square root and 16 more vector instructions)
+                asm volatile("");
                 uint32_t again = 0u;
                 v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, live_mask, tiny, again);
             }
@@ -518,7 +523,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         n_prod++;
                         const uint32_t r = base + lane, s = base >> 6;
                         float gx, gy, gz;
-                        gen_ray(u, ro, my_sx, my_sy, s >> 2, s & 3u, gx, gy, gz);
+                        gen_ray_at(u.inv_proj, u.inv_view, ro, my_sx, my_sy, s_off[2u * s], s_off[2u * s + 1u], gx, gy, gz);
                         const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
                         const bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
                                             ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
