@@ -358,6 +358,10 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     const bool chain_groups = chain && c->decoded.prunable && c->decoded.groups.size() == c->decoded.rec.size() / 2u;
     L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (chain_groups && chain_mode >= 2 ? 8u : 0u);
     c->last_loop = (L.flags & 8u) ? 2 : (L.flags & 4u) ? 1 : 0;
+    // programs that blend: a ray the plain miss tests cannot clear (every bound is inflated by the blend radius) gets the
+    // program run on lower bounds of its leaves along the ray.  RM_BOUND_WALK=0 (diagnostics) keeps the plain tests only.
+    static const bool bound_walk_on = !(std::getenv("RM_BOUND_WALK") && std::atoi(std::getenv("RM_BOUND_WALK")) == 0);
+    if (cull && c->decoded.bound_walk && bound_walk_on) L.flags |= 32u;
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
     if (!cull) L.n_cone = L.n_slab = 0u;
     const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;

@@ -36,6 +36,10 @@ struct RmDecoded {
     // Chain program: record 0 pushes a sphere / box, every later record is a sphere / box fused with a Union / Subtraction
     // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
     bool is_chain = false;
+    // The miss test of a ray can run the program on lower bounds (rm_kernel_v5.h "Miss test on lower bounds"): the program
+    // blends with SmoothUnion (otherwise the plain tests are as sharp), every leaf is a sphere or a box in world space (no
+    // transforms), and the accumulator machine never holds more than one spilled value
+    bool bound_walk = false;
     // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
     // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
     // on the structure only -- the generated code is compiled per structure -- the spheres on the parameters:
@@ -295,6 +299,11 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) != 0u;
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
+    d.bound_walk = d.smooth_slack > 0.0 && d.smooth_slack < 1.0e30 && !d.has_xforms && d.spill_depth <= 1u && d.scene_scale < 1.0e12f;
+    for (const RmRecord& r : d.rec) {
+        const uint32_t kind = RM_OP_KIND(r.op);
+        if (kind != RM_KIND_POP && kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) d.bound_walk = false;
+    }
     d.n_words = ptr;
     *out = std::move(d);
     return RM_OK;

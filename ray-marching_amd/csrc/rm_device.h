@@ -69,7 +69,7 @@ struct RmLaunch {
     const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:
                                // programs with transforms (their miss tests use these instead of the parameters)
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
-    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 3: ... with far pairs skipped (map_scene_chain_pruned)
+    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 3: ... with far pairs skipped (map_scene_chain_pruned); bit 5: miss test on lower bounds (RmDecoded::bound_walk)
     uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program
     float smooth_slack;        // sum of k/4 over SmoothUnion operators: how far they can lower the tree value
     float scene_scale;         // 1 + max |centre|_1 + |size|_1 over the primitives (RmDecoded::scene_scale)

@@ -560,6 +560,22 @@ inline const char* kernel_name() { return "rm_render_v5_spec"; }
 
 // mrec: the program decoded with its Material tags (empty for an untagged program): the kernel then gets the material
 // phase, with the walk generated as code when jit_knob RM_JIT_MATERIAL_WALK allows (default) and possible.
+// Whether a program of this STRUCTURE can meet the miss test on lower bounds (RmDecoded::bound_walk, which also looks at
+// the parameters): only then is the test compiled into its kernel -- it costs two or three registers the others need.
+inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
+    bool smooth = false;
+    int spilled = 0, depth = 0;
+    for (const RmRecord& r : rec) {
+        const uint32_t kind = RM_OP_KIND(r.op);
+        if (kind != RM_KIND_POP && kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) return false;
+        smooth = smooth || RM_OP_MODE(r.op) == RM_MODE_SMOOTH;
+        if (kind == RM_KIND_POP) spilled--;
+        else if (r.op & RM_OP_SPILL) spilled++;
+        depth = spilled > depth ? spilled : depth;
+    }
+    return smooth && depth <= 1;
+}
+
 inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, bool prune, std::string* out,
                             bool* walk_generated = nullptr) {
     const bool materials = !mrec.empty();
@@ -579,6 +595,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
+    if (structure_allows_bound_walk(rec)) s += "#define RM_JIT_BOUND_WALK 1\n";
     if (const char* pr = std::getenv("RM_JIT_PRIO_LONG_RAYS")) {  // experiment knob
         s += "#define RM_PRIO_LONG_RAYS ";
         s += std::to_string(std::atoi(pr));

@@ -332,6 +332,93 @@ RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float d
     return clear;
 }
 
+// ---- Miss test on lower bounds (programs with SmoothUnion; RmDecoded::bound_walk) -------------------------------
+// The plain tests clear a ray when it stays farther than the margin from EVERY primitive, and for a program that blends
+// the margin carries the blend's reach (RmDecoded::smooth_slack, = k for a chain of SmoothUnion(k)): a ray that passes one
+// primitive at 0.1 is marched although nothing else is within 0.5 of it and the tree value never drops below 0.1 there.
+// Sharper, and still exact: every operator admitted here is monotone non-decreasing in each operand --
+//     min(a, b), max(a, b), smin_k(a, b) = min(a, b) - h^2 k / 4 with h = max(k - |a - b|, 0) / k  (d/da, d/db in [0, 1])
+// -- except the right operand of a Subtraction, and max(a, -b) >= a.  So with c_i <= v_i(q) for every position q of the
+// half-line (c_i: how close the half-line comes to leaf i), running the PROGRAM on the c_i -- Subtraction keeping its left
+// operand -- gives L <= F(q) for every q of the half-line: if L exceeds the hit threshold (plus the same float slack as the
+// plain tests), no march position of the ray can register a hit (wgsl:97), whatever the steps, and the ray is shaded as
+// a miss.  Bounds along the half-line o + t d, |d| = 1, t >= 0:
+//     sphere  |q - c| - r >= dist(half-line, c) - r                     (exact: |m x d| if m.d > 0, else |m|)
+//     box     sdf_box >= Chebyshev distance to the box [c - h+, c + h+], h+ = max(h, 0): the smallest inflation delta at
+//             which the slab intervals [tn_i - delta / |d_i|, tf_i + delta / |d_i|] and t >= 0 have a common point, i.e.
+//             max over i != j of (tn_i - tf_j) / (1 / |d_i| + 1 / |d_j|) and over j of -tf_j |d_j|
+// All of it may use fused multiply-adds and approximate reciprocals: these are bounds, not values of the arithmetic
+// contract; every bound is lowered by 1e-5 of itself plus 2e-6 of the scene's scale, NaN becomes -3e38 (v_max drops a NaN
+// operand, a min over bounds must not).  Runs only for the rays the plain tests could not clear.
+template <class LoadRecord>
+RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, const V4& ro, float dx, float dy, float dz, float min_dist,
+                                    float scale) {
+    unit_dir(dx, dy, dz);
+    const float tiny = 1.0e-18f;  // |d_i| is clamped away from 0: 1 / |d_i| times a coordinate (< 1e12, RmDecoded::bound_walk) stays finite
+    const float ax = fmax_(__builtin_fabsf(dx), tiny), ay = fmax_(__builtin_fabsf(dy), tiny), az = fmax_(__builtin_fabsf(dz), tiny);
+    const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(ax, dx)), iy = __builtin_amdgcn_rcpf(__builtin_copysignf(ay, dy));
+    const float iz = __builtin_amdgcn_rcpf(__builtin_copysignf(az, dz));
+    const float wxy = (ax * ay) * __builtin_amdgcn_rcpf(ax + ay), wxz = (ax * az) * __builtin_amdgcn_rcpf(ax + az);
+    const float wyz = (ay * az) * __builtin_amdgcn_rcpf(ay + az);
+    const float lower = 2.0e-6f * scale;
+    const float inf = __uint_as_float(0x7F800000u);
+    float acc = inf, spilled = inf;
+    for (uint32_t i = 0u; i < n_rec; i++) {
+        uint32_t op;
+        float p[7];
+        load(i, op, p);
+        op = __builtin_amdgcn_readfirstlane(op);
+        const uint32_t kind = RM_OP_KIND(op), mode = RM_OP_MODE(op);
+        float a, b;
+        if (kind == RM_KIND_POP) {
+            a = spilled; b = acc;
+        } else {
+            const float mx = p[0] - ro.x, my = p[1] - ro.y, mz = p[2] - ro.z;
+            if (kind == RM_KIND_SPHERE) {
+                const float cx = __builtin_fmaf(my, dz, -(mz * dy)), cy = __builtin_fmaf(mz, dx, -(mx * dz)), cz = __builtin_fmaf(mx, dy, -(my * dx));
+                const float perp2 = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
+                const float mm = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+                const float along = __builtin_fmaf(mz, dz, __builtin_fmaf(my, dy, mx * dx));
+                const float dist = __builtin_amdgcn_sqrtf(along > 0.0f ? perp2 : mm);
+                b = dist * (1.0f - 1.0e-5f) - p[3];
+            } else {  // RM_KIND_BOX
+                const float hx = fmax_(p[3], 0.0f), hy = fmax_(p[4], 0.0f), hz = fmax_(p[5], 0.0f);
+                const float x1 = (mx - hx) * ix, x2 = (mx + hx) * ix, y1 = (my - hy) * iy, y2 = (my + hy) * iy;
+                const float z1 = (mz - hz) * iz, z2 = (mz + hz) * iz;
+                const float nx = fmin_(x1, x2), fx = fmax_(x1, x2), ny = fmin_(y1, y2), fy = fmax_(y1, y2);
+                const float nz = fmin_(z1, z2), fz = fmax_(z1, z2);
+                const float d0 = fmax_((nx - fy) * wxy, (ny - fx) * wxy);
+                const float d1 = fmax_((nx - fz) * wxz, (nz - fx) * wxz);
+                const float d2 = fmax_((ny - fz) * wyz, (nz - fy) * wyz);
+                const float d3 = fmax_(-fx * ax, fmax_(-fy * ay, -fz * az));
+                // (every product is finite: coordinates < 1e12 -- the caller checks the scale -- times 1 / |d_i| <= 1e18; a NaN
+                // term dropped by v_max could only lower the maximum)
+                const float delta = fmax_(fmax_(d0, d1), fmax_(d2, d3));
+                b = delta * (1.0f - 1.0e-5f);
+            }
+            b = fmax_(b - (lower + 1.0e-5f * __builtin_fabsf(b)), -3.0e38f);  // NaN -> -3e38
+            if (op & RM_OP_SPILL) spilled = acc;
+            a = acc;
+        }
+        if (mode == RM_MODE_PUSH) acc = b;
+        else if (mode == RM_MODE_UNION) acc = fmin_(a, b);
+        else if (mode == RM_MODE_SUB) acc = a;                      // max(a, -b) >= a
+        else if (mode == RM_MODE_INTER) acc = fmax_(a, b);
+        else {  // RM_MODE_SMOOTH
+            const float kk = p[0];
+            float v = fmin_(a, b);
+            if (kk > 0.0f) {
+                const float h = fmax_(kk - __builtin_fabsf(a - b), 0.0f) * __builtin_amdgcn_rcpf(kk);
+                v = v - ((h * h) * kk) * 0.25f;
+                v = v - (1.0e-6f * (__builtin_fabsf(v) + kk));
+            }
+            acc = fmax_(v, -3.0e38f);  // NaN (k = inf) -> -3e38
+        }
+    }
+    const float margin = fmax_(min_dist, 0.0f) * 1.01f + 1.0e-4f * scale;
+    return acc > margin;  // NaN -> false
+}
+
 // Work list produced by the pre-pass (rm_tile_pre_v5 + rm_tile_sort_v5), one per frame.
 struct V5Work {
     const uint32_t* order;  // [n_frames][n_tiles] ids of the tiles that need marching, heaviest first
@@ -423,6 +510,18 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     if constexpr (PROG_IN_LDS) prog.base = lprog;
     else prog.base = L.prog;
 
+    // record i of the program as (opcode, parameters), wherever this kernel keeps it (SPEC: the rotated LDS copy)
+    auto load_record = [&](uint32_t i, uint32_t& op, float (&p)[7]) {
+        if constexpr (PROG_IN_LDS) {
+            const uint32_t* r = lprog + 8u * i;
+            op = r[SPEC ? 7u : 0u];
+#pragma unroll
+            for (int k = 0; k < 7; k++) p[k] = __uint_as_float(r[(SPEC ? 0u : 1u) + (uint32_t)k]);
+        } else {
+            prog.load(i, op, p);
+        }
+    };
+    const float bound_scale = prune_scale + L.smooth_slack;  // scale of the coordinates the bounds are computed from
     const LdsF lprog_v = lds_vector_base(lprog);  // SPEC: the program's LDS copy, base address in a VGPR (see LdsF)
     uint32_t n_eval = 0u;  // diagnostics (pruned kernels compiled with statistics): leaves actually evaluated, per wave
     // map_scene (wgsl:187-203) at one point per lane
@@ -525,8 +624,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         float gx, gy, gz;
                         gen_ray_at(u.inv_proj, u.inv_view, ro, my_sx, my_sy, s_off[2u * s], s_off[2u * s + 1u], gx, gy, gz);
                         const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
-                        const bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
-                                            ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+                        bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
+                                      ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+#if !defined(RM_JIT_TU) || defined(RM_JIT_BOUND_WALK)  // a generated kernel carries it only if its program's structure can use it
+                        if ((L.flags & 32u) && *s_veto == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
+                            culled = culled || ray_misses_by_bounds_v5(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
+#endif
                         if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                         const unsigned long long keep = __ballot(!culled);
                         if (!culled) {

@@ -833,6 +833,76 @@ def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
     res.resize_command_buffer(1024)
 
 
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5", "v5_lds", "v5_spec"])
+def test_miss_test_on_lower_bounds_is_exact(res, oracle, kernel):
+    """Programs that blend (SmoothUnion) get a second, sharper miss test for the rays the inflated bounds cannot clear:
+    the program run on lower bounds of its leaves along the ray (rm_kernel_v5.h "Miss test on lower bounds").  Random
+    chains of spheres and boxes joined by SmoothUnion / Union / Subtraction / Intersection -- k small, large, zero,
+    negative; flat, degenerate and negative sizes; everything 1000 units from the origin -- from eight cameras (inside a
+    solid, grazing, top-down, far): culling on == culling off == oracle.  A balanced tree of blends (needs a deeper value
+    stack) and a blended cylinder keep the plain tests and must still be right."""
+    rng = np.random.default_rng(2024)
+    W, H = 64, 40
+    lim = (0.01, 100.0, 80)
+    res.resize_command_buffer(4096)
+
+    def random_chain(offset, n):
+        t = scenes._Tab()
+        acc = None
+        for j in range(n):
+            c = rng.uniform(-1.6, 1.6, 3) + np.array(offset)
+            if rng.random() < 0.5:
+                leaf = t.sphere(tuple(c), float(rng.choice([rng.uniform(0.2, 0.6), 0.0, -0.15], p=[0.8, 0.1, 0.1])))
+            else:
+                h = rng.uniform(0.1, 0.6, 3)
+                if rng.random() < 0.2:
+                    h[rng.integers(3)] = rng.choice([0.0, -0.1])
+                leaf = t.box(tuple(c), tuple(h))
+            if acc is None:
+                acc = leaf
+                continue
+            r = rng.random()
+            if r < 0.6:
+                acc = t.smooth_union(acc, leaf, float(rng.choice([0.25, 0.05, 0.9, 0.0, -0.3])))
+            elif r < 0.75:
+                acc = t.op(scenes.UNION, acc, leaf)
+            elif r < 0.9:
+                acc = t.op(scenes.SUBTRACTION, acc, leaf)
+            else:
+                acc = t.op(scenes.INTERSECTION, acc, leaf)
+        return t.nodes, acc
+
+    programs = [("chain%d" % i, (0.0, 0.0, 0.0), random_chain((0.0, 0.0, 0.0), n)) for i, n in enumerate((2, 5, 9, 14))]
+    programs.append(("far_from_origin", (1000.0, -2000.0, 500.0), random_chain((1000.0, -2000.0, 500.0), 8)))
+    programs.append(("config3", (0.0, 0.0, 0.0), scenes.EXT_SCENES["g32s"]()))
+    t = scenes._Tab()
+    level = [t.sphere(tuple(rng.uniform(-1.5, 1.5, 3)), 0.4) for _ in range(8)]
+    while len(level) > 1:
+        level = [t.smooth_union(level[i], level[i + 1], 0.3) for i in range(0, len(level), 2)]
+    programs.append(("balanced_blends", (0.0, 0.0, 0.0), (t.nodes, level[0])))
+    t = scenes._Tab()
+    programs.append(("blended_cylinder", (0.0, 0.0, 0.0),
+                     (t.nodes, t.smooth_union(t.sphere((-0.5, 0, 0), 0.6), t.cylinder((0.6, 0.0, 0.1), 0.4, 0.7), 0.3))))
+    for name, target, (nodes, root) in programs:
+        cc, w = oracle.serialize(nodes, root)
+        for cam in sorted(CULL_CAMERAS):
+            spec = dict(CULL_CAMERAS[cam])
+            if "target" not in spec:
+                spec["target"] = target
+            elif name != "far_from_origin":
+                continue
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), **spec)
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            res.set_option(_ffi.RM_OPT_CULL, 0)
+            off = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_CULL, 1)
+            on = res.draw(W, H)
+            assert off.tobytes() == ref.tobytes(), (name, cam, "cull off")
+            assert on.tobytes() == ref.tobytes(), (name, cam, "cull on")
+    res.resize_command_buffer(1024)
+
+
 def test_draw_is_stream_capturable(oracle):
     """After its first (allocating, compiling) draw of a size, rm_draw with a device destination issues nothing but
     kernel launches on the caller's stream: it can be captured into a HIP graph and replayed."""
