@@ -4,6 +4,7 @@
 // post-order).  Host-only, no HIP.
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -93,9 +94,13 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
     }
     std::vector<RmXformScope> scopes;
     std::vector<double> slack;  // per value-stack entry, see RmDecoded::smooth_slack
+    std::vector<size_t> first;  // per value-stack entry: index of the first record of the sub-tree that produced it
     auto combine = [&](uint32_t op_mode, double k) {  // pops b and a, pushes the operator's slack
         const double sb = slack.back(); slack.pop_back();
         const double sa = slack.back(); slack.pop_back();
+        const size_t fb = first.back(); first.pop_back();  // a's first record stays: the result spans both
+        if (op_mode == RM_MODE_SUB)  // everything b was built from: out of the miss-test tables (RM_OP_NOCULL)
+            for (size_t j = fb; j < d.rec.size(); j++) d.rec[j].op |= RM_OP_NOCULL;
         double sv = sa > sb ? sa : sb;
         if (op_mode == RM_MODE_SMOOTH) {
             if (k > 0.0) sv = (sa == 0.0 || sb == 0.0) ? (sv > k ? sv : k) : sv + 0.25 * k;
@@ -221,13 +226,14 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
                 else if (words[ptr] == RM_CMD_INTERSECTION) { mode = RM_MODE_INTER; d.has_extensions = true; }
             }
             slack.push_back(0.0);
+            first.push_back(d.rec.size());
             if (mode != RM_MODE_PUSH) {
                 combine(mode, 0.0);
                 ptr++;  // consume the operator: depth is unchanged (push, then pop 2 push 1)
                 i++;
                 if (depth + 1 > 32) return RM_ERR_STACK_OVERFLOW;  // the reference machine peaks one higher
                 if (depth + 1 > d.max_depth) d.max_depth = depth + 1;
-                r.op = RM_OP(kind, mode, 0);
+                r.op = RM_OP(kind, mode, 0) | (mode == RM_MODE_SUB ? (uint32_t)RM_OP_NOCULL : 0u);  // this leaf IS the right operand
                 if ((kind == RM_KIND_SPHERE || kind == RM_KIND_BOX) && (mode == RM_MODE_UNION || mode == RM_MODE_SUB))
                     r.op |= ((kind == RM_KIND_SPHERE ? 1u : 2u) + (mode == RM_MODE_SUB ? 2u : 0u)) << 16;  // RM_OP_FASTCLASS
             } else {
@@ -262,6 +268,23 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
     }
     if (!scopes.empty()) return RM_ERR_TRANSFORM;
     if (cmd_count && depth < 1) return RM_ERR_EMPTY_RESULT;
+    // Table slots of the primitives the miss tests have to clear.  A program with transforms keeps one cone per bounded
+    // primitive (their slots index `bounds`, filled above); otherwise subtracted primitives get none (RM_OP_NOCULL).
+    static const bool keep_subtracted = std::getenv("RM_CULL_SUBTRACTED") && std::atoi(std::getenv("RM_CULL_SUBTRACTED")) == 0;  // A/B
+    if (d.has_xforms || keep_subtracted) {
+        for (RmRecord& r : d.rec) r.op &= ~(uint32_t)RM_OP_NOCULL;
+    }
+    if (d.has_xforms) {
+    } else {
+        d.n_sphere = d.n_box = 0u;
+        for (RmRecord& r : d.rec) {
+            const uint32_t kind = RM_OP_KIND(r.op);
+            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX && kind != RM_KIND_CYLINDER) { r.op &= ~(uint32_t)RM_OP_NOCULL; continue; }
+            uint32_t slot = 0u;
+            if (!(r.op & RM_OP_NOCULL)) slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : d.n_box++;
+            std::memcpy(&r.p[6], &slot, 4);
+        }
+    }
     if (d.prunable) {  // group spheres, see RmDecoded::groups
         const RmRecord* first = nullptr;
         for (const RmRecord& r : d.rec) {

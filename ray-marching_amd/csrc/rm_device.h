@@ -38,6 +38,10 @@ enum : uint32_t { RM_MAX_XFORM_DEPTH = 8 };
 #define RM_OP_KIND(op) ((op) & 7u)
 #define RM_OP_MODE(op) (((op) >> 3) & 7u)
 enum : uint32_t { RM_OP_SPILL = 1u << 6 };
+// A leaf inside the right operand of a Subtraction has no entry in the miss-test tables: max(a, -b) >= a, so a march position
+// registers a hit (wgsl:97) only within the margin of a leaf of the LEFT operand, however close the ray comes to b
+// (rm_decode.h, rm_kernel_v5.h cull_build_v5)
+enum : uint32_t { RM_OP_NOCULL = 1u << 7 };
 // Interpreter fast class (bits 16-18; generated code and the v1 kernel ignore it): the four record shapes that make up a
 // left-deep chain -- a sphere / box leaf fused with the Union / Subtraction that consumes it, on a live accumulator, no
 // stack traffic -- are dispatched with two decisions instead of the generic kind / spill / mode ladder (rm_interp.h).

@@ -259,6 +259,7 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
     uint32_t kind = RM_OP_KIND(rec.op);
     if (kind == RM_KIND_POP || kind == RM_KIND_XFORM) return;
     if (kind == RM_KIND_PLANE) { *veto = 1u; return; }  // unbounded primitive: nothing can be culled
+    if (rec.op & RM_OP_NOCULL) return;  // subtracted: a hit needs the left operand's surface, whatever this one does
     const float inf = __uint_as_float(0x7F800000u);
     const uint32_t slot = __float_as_uint(rec.p[6]);
     float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2], sphere_r = rec.p[3];

@@ -903,6 +903,49 @@ def test_miss_test_on_lower_bounds_is_exact(res, oracle, kernel):
     res.resize_command_buffer(1024)
 
 
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE], ids=["v5_lds", "v5_spec", "v5_spec_prune"])
+def test_subtracted_primitives_leave_the_miss_tests(res, oracle, kernel):
+    """max(a, -b) >= a: a march position registers a hit only near a leaf of a Subtraction's LEFT operand, so the leaves of
+    its right operand -- a single primitive or a whole sub-tree -- have no entry in the miss-test tables (rm_decode.h,
+    RM_OP_NOCULL) and a ray that only comes near them is not marched.  Subtractors that carve visible holes, that float in
+    empty space, that contain the camera; sub-trees on the right (a union, another subtraction: its own right operand then
+    counts positively in the value but is still dropped from the tables, which is only conservative); culling on == off ==
+    oracle from eight cameras."""
+    W, H = 64, 40
+    lim = (0.01, 100.0, 80)
+    res.resize_command_buffer(4096)
+    U, S, I = scenes.UNION, scenes.SUBTRACTION, scenes.INTERSECTION
+    cases = {}
+    t = scenes._Tab()   # a block with a spherical bite, plus a subtractor far from everything
+    cases["bite_and_lonely_subtractor"] = (t.nodes, t.op(S, t.op(S, t.box((0, 0, 0), (1.0, 0.6, 0.8)), t.sphere((0.9, 0.5, 0.0), 0.7)),
+                                                         t.sphere((-2.5, 1.0, 0.5), 0.8)))
+    t = scenes._Tab()   # right operand is a union of two primitives
+    cases["minus_union"] = (t.nodes, t.op(S, t.sphere((0, 0, 0), 1.2), t.op(U, t.box((0.8, 0, 0), (0.6, 0.3, 1.5)), t.sphere((-1.0, 0.8, 0), 0.6))))
+    t = scenes._Tab()   # right operand is itself a subtraction: a - (b - c) = max(a, min(-b, c))
+    cases["minus_subtraction"] = (t.nodes, t.op(S, t.box((0, 0, 0), (1.2, 1.0, 1.0)), t.op(S, t.sphere((0.6, 0.4, 0.2), 1.0), t.box((0.6, 0.4, 0.2), (0.4, 0.4, 0.4)))))
+    t = scenes._Tab()   # a union whose second member is a carved block; the subtractor also pokes out into empty space
+    cases["union_of_carved"] = (t.nodes, t.op(U, t.sphere((-1.4, 0, 0), 0.6), t.op(S, t.box((0.8, 0, 0), (0.7, 0.7, 0.7)), t.box((1.6, 0.5, 0), (0.9, 0.3, 0.3)))))
+    t = scenes._Tab()   # intersection with a carved operand
+    cases["intersection_of_carved"] = (t.nodes, t.op(I, t.sphere((0, 0, 0), 1.1), t.op(S, t.box((0, 0, 0), (0.9, 0.9, 0.9)), t.sphere((0, 1.0, 0), 0.6))))
+    cases["g32"] = scenes.g32()
+    cases["g8"] = scenes.g8()
+    for name, (nodes, root) in cases.items():
+        cc, w = oracle.serialize(nodes, root)
+        for cam in sorted(CULL_CAMERAS):
+            if "target" in CULL_CAMERAS[cam]:
+                continue
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), **CULL_CAMERAS[cam])
+            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+            res.set_option(_ffi.RM_OPT_CULL, 0)
+            off = res.draw(W, H)
+            res.set_option(_ffi.RM_OPT_CULL, 1)
+            on = res.draw(W, H)
+            assert off.tobytes() == ref.tobytes(), (name, cam, "cull off")
+            assert on.tobytes() == ref.tobytes(), (name, cam, "cull on")
+    res.resize_command_buffer(1024)
+
+
 def test_draw_is_stream_capturable(oracle):
     """After its first (allocating, compiling) draw of a size, rm_draw with a device destination issues nothing but
     kernel launches on the caller's stream: it can be captured into a HIP graph and replayed."""
