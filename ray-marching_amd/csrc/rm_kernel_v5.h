@@ -1008,6 +1008,35 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     const uint32_t pending = (uint32_t)__popcll(__ballot(!clear));
     if (lane == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = pending;  // 0 = finished here
     if (pending != 0u) return;
+    // Sky: a sample whose ray points away from the floor plane (t <= 0 in wgsl:120-121) is black, and the sum of sixteen
+    // zeros is zero.  pt_world.y - ro.y is affine in the sample's screen offset, so its sign over the 4 x 4 grid is decided at
+    // the four corner samples up to rounding; with the camera above the plane (-1.5 - ro.y < 0), "all four corners point up by
+    // more than the rounding can move any of the sixteen" means dy > 0, t < 0 for all of them.  The margin is 1e-5 of `mag`,
+    // the sum of the absolute values of every term the two mat-vecs add up for the y component (each of the ~30 roundings
+    // on the way is <= 6e-8 of a partial sum, hence of mag; interior and corner values each move by that, the affine
+    // argument needs twice it).  A tile whose 64 pixels are all such writes zeros and skips the loop below (about half of
+    // the clear tiles of the metric frame).  Anything non-finite fails the comparison and takes the loop.
+    {
+        float lo = __uint_as_float(0x7F800000u);
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++) {
+            float ex, ey, ez;
+            gen_ray_unnormalized(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex, ey, ez);
+            lo = ey < lo ? ey : lo;
+            if (!(ey == ey)) lo = ey;  // a NaN sticks and makes the test below false
+        }
+        const float bx = __builtin_fabsf(sx) + __builtin_fabsf(s_off[0]), by = __builtin_fabsf(sy) + __builtin_fabsf(s_off[1]);  // sample (0, 0) has the largest offsets
+        float mag = __builtin_fabsf(ro.y);
+#pragma unroll
+        for (int k = 0; k < 4; k++)  // |inv_view row y| . (|inv_proj| (|x|, |y|, 1, 1))
+            mag += __builtin_fabsf(u.inv_view[1 + 4 * k]) * (((__builtin_fabsf(u.inv_proj[k]) * bx + __builtin_fabsf(u.inv_proj[k + 4]) * by) +
+                                                              __builtin_fabsf(u.inv_proj[k + 8])) + __builtin_fabsf(u.inv_proj[k + 12]));
+        const bool sky = (-1.5f - ro.y) < 0.0f && lo > 1.0e-5f * mag;
+        if (__ballot(!sky) == 0ull) {
+            if (tx < L.W && ty < L.rows) store_pixel(L, blockIdx.z, (size_t)ty * L.W + tx, 0.0f, 0.0f, 0.0f);  // 0 / 16 = 0 (wgsl:73-75)
+            return;
+        }
+    }
     // This loop is most of the pre-pass (60 % of the metric frame's pixels x 16 samples).  Everything that does not depend on
     // the pixel is taken out of it: the sample offsets (two divisions each) come from the table above, the matrices sit in
     // vector registers (32 of them; as scalar operands every multiply of the two mat-vecs would issue at half rate), and the
