@@ -117,7 +117,8 @@ enum rm_option {
                               took longest in the context's previous draw of the same shape first -- consecutive frames
                               of a view look alike, and a kernel that ends on its shortest tiles has no tail
                               (one frame at a time: +6-9 %); the first draw of a shape falls back to 1 */
-    RM_OPT_WAVES_PER_TILE = 7, /* waves (1, 2, 4, 8; default 4) sharing one tile's ray pool */
+    RM_OPT_WAVES_PER_TILE = 7, /* waves (1, 2, 4, 8) sharing one tile's ray pool; 0 (default): 4, or 8 for a launch of at most
+                                  6000 tiles, whose duration is the latency of its heaviest tile */
     RM_OPT_WAVE_STATS = 6, /* diagnostics: the v5 kernels record per-wave timing/loop statistics (rm_read_wave_stats) */
     RM_OPT_OUTPUT_FORMAT = 10, /* enum rm_format: what rm_draw / rm_draw_strips / rm_draw_batch write (default RM_FORMAT_RGBA32F).
                                   The 8-bit formats are the output stage of SURVEY 8(f)-3: the reference's own colour target is

@@ -79,7 +79,7 @@ struct rm_ctx {
     bool cull = true;
     int balance = 3;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first,
                       // 3 (default) longest tiles of the previous draw of the same shape first
-    int waves_per_tile = 4;
+    int waves_per_tile = 0;  // 0: by the size of the launch (launch_v5)
     bool wave_stats = false;
     unsigned long long* d_stats = nullptr;
     size_t d_stats_bytes = 0, stats_valid_bytes = 0;
@@ -430,7 +430,12 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
 }
 
 int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStream_t s) {
-    int wpt = c->waves_per_tile;
+    // Waves per tile.  A march launch lasts at least as long as its heaviest tile (1024 rays through one workgroup); four waves
+    // per tile give the best throughput when there are tiles to fill the chip with, eight halve that latency and win once a
+    // launch has fewer tiles than the chip has room for -- one GPU's share of a frame tiled over eight (DESIGN.md section 7:
+    // 144 rows of 1080p: 0.095 -> 0.084 ms per frame; the whole frame: 0.546 -> 0.613).
+    const size_t launch_tiles = (size_t)((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u) * n_frames;
+    int wpt = c->waves_per_tile != 0 ? c->waves_per_tile : (launch_tiles <= 6000u ? 8 : 4);
     const size_t cull_bytes = L.n_rec <= 256u ? (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u : 0u;  // tables exist up to 256 records
     const size_t prog_bytes = (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord);
     const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
@@ -965,7 +970,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
         c->specialize = (int)value;
         return RM_OK;
     case RM_OPT_WAVES_PER_TILE:
-        if (value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RM_ERR_ARG, "waves_per_tile must be 1, 2, 4 or 8");
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8) return fail(c, RM_ERR_ARG, "waves_per_tile must be 0 (automatic), 1, 2, 4 or 8");
         c->waves_per_tile = (int)value;
         return RM_OK;
     case RM_OPT_REFILL_MIN:

@@ -170,6 +170,10 @@ def test_waves_per_tile_variants_and_batch(res, oracle):
     assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1
     for i, f in enumerate(frames):
         assert batch[i].tobytes() == oracle.render(f, LIM, cc, w, W, H, threads=4).tobytes()
+    with pytest.raises(_ffi.RmError):
+        res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, 3)
+    res.set_option(_ffi.RM_OPT_WAVES_PER_TILE, 0)      # back to the default: by the size of the launch (8 here, 4 for a full frame)
+    assert res.draw(W, H).tobytes() == ref.tobytes()
 
 
 def test_full_size_metric_config_specialised_vs_interpreter(res, oracle):
