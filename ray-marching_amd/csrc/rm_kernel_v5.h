@@ -351,10 +351,15 @@ RM_DEV bool ray_misses_scene_v5(const CullTables& T, float dx, float dy, float d
 // All of it may use fused multiply-adds and approximate reciprocals: these are bounds, not values of the arithmetic
 // contract; every bound is lowered by 1e-5 of itself plus 2e-6 of the scene's scale, NaN becomes -3e38 (v_max drops a NaN
 // operand, a min over bounds must not).  Runs only for the rays the plain tests could not clear.
-template <class LoadRecord>
+// CONE (the pre-pass): (dx, dy, dz) is the unit centre direction of a pixel whose sixteen sample directions e all satisfy
+// |e - c| <= rho.  The point at distance t on such a ray is within t rho of the centre ray's, leaves are 1-Lipschitz, and
+// beyond T = |m| + R + max(c_i, 0) a leaf of bounding radius R around m is farther than max(c_i, 0) anyway, so
+//     c_i(pixel) >= c_i(centre ray) - rho (|m| + R + max(c_i, 0)),
+// the same inflation the plain pixel test applies to its cones and slabs.
+template <bool CONE, class LoadRecord>
 RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, const V4& ro, float dx, float dy, float dz, float min_dist,
-                                    float scale) {
-    unit_dir(dx, dy, dz);
+                                    float scale, float rho = 0.0f) {
+    if (!CONE) unit_dir(dx, dy, dz);
     const float tiny = 1.0e-18f;  // |d_i| is clamped away from 0: 1 / |d_i| times a coordinate (< 1e12, RmDecoded::bound_walk) stays finite
     const float ax = fmax_(__builtin_fabsf(dx), tiny), ay = fmax_(__builtin_fabsf(dy), tiny), az = fmax_(__builtin_fabsf(dz), tiny);
     const float ix = __builtin_amdgcn_rcpf(__builtin_copysignf(ax, dx)), iy = __builtin_amdgcn_rcpf(__builtin_copysignf(ay, dy));
@@ -375,15 +380,18 @@ RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, cons
             a = spilled; b = acc;
         } else {
             const float mx = p[0] - ro.x, my = p[1] - ro.y, mz = p[2] - ro.z;
+            const float mm = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+            float reach;  // CONE: bounding radius of the leaf
             if (kind == RM_KIND_SPHERE) {
                 const float cx = __builtin_fmaf(my, dz, -(mz * dy)), cy = __builtin_fmaf(mz, dx, -(mx * dz)), cz = __builtin_fmaf(mx, dy, -(my * dx));
                 const float perp2 = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
-                const float mm = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
+                reach = fmax_(p[3], 0.0f);
                 const float along = __builtin_fmaf(mz, dz, __builtin_fmaf(my, dy, mx * dx));
                 const float dist = __builtin_amdgcn_sqrtf(along > 0.0f ? perp2 : mm);
                 b = dist * (1.0f - 1.0e-5f) - p[3];
             } else {  // RM_KIND_BOX
                 const float hx = fmax_(p[3], 0.0f), hy = fmax_(p[4], 0.0f), hz = fmax_(p[5], 0.0f);
+                reach = (hx + hy) + hz;  // >= |h|
                 const float x1 = (mx - hx) * ix, x2 = (mx + hx) * ix, y1 = (my - hy) * iy, y2 = (my + hy) * iy;
                 const float z1 = (mz - hz) * iz, z2 = (mz + hz) * iz;
                 const float nx = fmin_(x1, x2), fx = fmax_(x1, x2), ny = fmin_(y1, y2), fy = fmax_(y1, y2);
@@ -397,6 +405,7 @@ RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, cons
                 const float delta = fmax_(fmax_(d0, d1), fmax_(d2, d3));
                 b = delta * (1.0f - 1.0e-5f);
             }
+            if (CONE) b = b - (rho * 1.00001f) * ((__builtin_amdgcn_sqrtf(mm) * 1.00001f + reach) + fmax_(b, 0.0f));
             b = fmax_(b - (lower + 1.0e-5f * __builtin_fabsf(b)), -3.0e38f);  // NaN -> -3e38
             if (op & RM_OP_SPILL) spilled = acc;
             a = acc;
@@ -629,7 +638,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                                       ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
 #if !defined(RM_JIT_TU) || defined(RM_JIT_BOUND_WALK)  // a generated kernel carries it only if its program's structure can use it
                         if ((L.flags & 32u) && *s_veto == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
-                            culled = culled || ray_misses_by_bounds_v5(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
+                            culled = culled || ray_misses_by_bounds_v5<false>(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
 #endif
                         if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                         const unsigned long long keep = __ballot(!culled);
@@ -904,8 +913,9 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 constexpr uint32_t V5_PRE_TILES = 4u;  // tiles (= waves) per pre-pass workgroup
 
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
+// cone_out: (unit centre direction, rho) of the pixel's sixteen sample directions; rho = NaN when the cone is not usable
 RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const rm_uniforms& u, const V4& ro, float sx,
-                                  float sy) {
+                                  float sy, float (&cone_out)[4]) {
     float cx = 0.0f, cy = 0.0f, cz = 0.0f, ex[4], ey[4], ez[4];
 #pragma unroll
     for (uint32_t c = 0; c < 4u; c++) {
@@ -926,6 +936,8 @@ RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const 
     bool clear = *T.veto == 0u && rho < 0.05f;
 #pragma unroll
     for (uint32_t c = 0; c < 4u; c++) clear = clear && (ex[c] - cx) * (ex[c] - cx) < 1.0f && (ey[c] - cy) * (ey[c] - cy) < 1.0f && (ez[c] - cz) * (ez[c] - cz) < 1.0f;
+    cone_out[0] = cx; cone_out[1] = cy; cone_out[2] = cz;
+    cone_out[3] = clear ? rho : __uint_as_float(0x7FC00000u);  // (clear so far: the cone itself is valid)
     for (uint32_t k = 0; k < T.n_cone; k++) {
         const float4 a = T.cone[k];  // wave-uniform address: LDS broadcast
         const float t = __builtin_fmaf(aux[k].x, rho, __builtin_fmaf(a.z, cz, __builtin_fmaf(a.y, cy, a.x * cx)));
@@ -1004,7 +1016,23 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     bool clear;
     if (L.max_iter == 0u) clear = true;  // no march step is ever taken: every ray is a miss (wgsl:92)
     else if (!tables) clear = false;
-    else clear = pixel_misses_scene_v5(cullt, t_aux, u, ro, sx, sy);
+    else {
+        float cone[4];
+        clear = pixel_misses_scene_v5(cullt, t_aux, u, ro, sx, sy, cone);
+        // a program that blends: the pixels the inflated bounds could not clear get the program run on lower bounds of its
+        // leaves over the pixel's cone ("Miss test on lower bounds"; the march kernel repeats it per ray for what is left)
+        const float bound_scale = (L.scene_scale + L.smooth_slack) + ((__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y)) + __builtin_fabsf(ro.z));
+        if ((L.flags & 32u) && *s_veto == 0u && bound_scale < 1.0e12f && __ballot(!clear && cone[3] == cone[3]) != 0ull) {
+            auto load_record = [&](uint32_t i, uint32_t& op, float (&p)[7]) {
+                const RmRecord& r = L.prog[i];  // wave-uniform address: scalar loads
+                op = r.op;
+#pragma unroll
+                for (int k = 0; k < 7; k++) p[k] = r.p[k];
+            };
+            const bool by_bounds = ray_misses_by_bounds_v5<true>(load_record, L.n_rec, ro, cone[0], cone[1], cone[2], L.min_dist, bound_scale, cone[3]);
+            clear = clear || (cone[3] == cone[3] && by_bounds);
+        }
+    }
     const uint32_t pending = (uint32_t)__popcll(__ballot(!clear));
     if (lane == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = pending;  // 0 = finished here
     if (pending != 0u) return;
