@@ -62,15 +62,16 @@ for world in [int(x) for x in a.worlds.split(",")]:
                 frame(k)
                 k += 1
             torch.cuda.synchronize()
-        runs = []
+        runs, issue = [], []
         for _ in range(5):
             t0 = time.perf_counter()
             for k in range(K):
                 frame(k)
+            issue.append((time.perf_counter() - t0) / K * 1e3)   # host time to issue a frame (the queue absorbs it while it is shorter)
             torch.cuda.synchronize()
             runs.append((time.perf_counter() - t0) / K * 1e3)
         ms = sorted(runs)[len(runs) // 2]
-        print("F=%d wpt=%d strips of %d rows, N=%d rank %d: %4d rows  %.3f ms per frame (median of 5 runs, min %.3f)%s -> %6.0f Mpx/s for the job"
-              % (F, a.waves_per_tile, SR, world, rank, rows, ms, min(runs), " incl. D2H of the strips" if a.gather else "", W * H / ms / 1e3), flush=True)
+        print("F=%d wpt=%d strips of %d rows, N=%d rank %d: %4d rows  %.3f ms per frame (median of 5 runs, min %.3f)%s -> %6.0f Mpx/s for the job  (host issue %.3f ms per frame)"
+              % (F, a.waves_per_tile, SR, world, rank, rows, ms, min(runs), " incl. D2H of the strips" if a.gather else "", W * H / ms / 1e3, sorted(issue)[len(issue) // 2]), flush=True)
         for r in ctxs:
             r.close()
