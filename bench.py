@@ -465,7 +465,9 @@ def valu_view(args, res, march_ms, evals, words):
         f_prog += fl
         i += 1 + n
     out["flops_per_eval_reference"] = f_prog
-    out["algorithmic_TFLOPs"] = evals * f_prog / (march_ms * 1e-3) / 1e12
+    # what the REFERENCE's evaluation count would amount to in this kernel's time: NOT a rate the chip reaches (it can exceed
+    # the vector peak) -- the exact miss tests and the far-primitive pruning skip most of those evaluations
+    out["reference_equivalent_TFLOPs"] = evals * f_prog / (march_ms * 1e-3) / 1e12
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pmc = json.load(fh).get("%s_%dx%d_%d_valu" % (args.scene, args.width, args.height, args.max_iter))
