@@ -101,6 +101,19 @@ pub const RM_INFO_JIT_COMPILE_MS: c_int = 8;
 pub const RM_INFO_PRUNED: c_int = 9;
 pub const RM_INFO_INTERPRETER_LOOP: c_int = 10;
 
+// enum rm_program_fact: indices into the array rm_program_info fills
+pub const RM_PROGRAM_RECORDS: usize = 0;
+pub const RM_PROGRAM_CONES: usize = 1;
+pub const RM_PROGRAM_SLABS: usize = 2;
+pub const RM_PROGRAM_SUBTRACTED_LEAVES: usize = 3;
+pub const RM_PROGRAM_GROUPS: usize = 4;
+pub const RM_PROGRAM_SPILL_DEPTH: usize = 5;
+pub const RM_PROGRAM_IS_CHAIN: usize = 6;
+pub const RM_PROGRAM_PRUNABLE: usize = 7;
+pub const RM_PROGRAM_BOUND_WALK: usize = 8;
+pub const RM_PROGRAM_HAS_XFORMS: usize = 9;
+pub const RM_PROGRAM_FACTS: usize = 10;
+
 /// `RM_JIT_PRUNE`: OR into `waves_per_tile` of rm_jit_source / rm_jit_compile.
 pub const RM_JIT_PRUNE: c_int = 0x100;
 
@@ -126,6 +139,7 @@ extern "C" {
     pub fn rm_resize_command_buffer(ctx: *mut rm_ctx, bytes: u64) -> c_int;
     pub fn rm_validate(ctx: *mut rm_ctx) -> c_int;
     pub fn rm_validate_program(cmd_count: u32, words: *const u32, n_words: u32, out_max_depth: *mut u32) -> c_int;
+    pub fn rm_program_info(cmd_count: u32, words: *const u32, n_words: u32, out: *mut u32, n_out: u32) -> c_int;
     pub fn rm_draw(ctx: *mut rm_ctx, w: u32, h: u32, row0: u32, rows: u32, out_rgba: *mut f32, out_is_device: c_int,
                    stream: *mut c_void) -> c_int;
     pub fn rm_draw_strips(ctx: *mut rm_ctx, w: u32, h: u32, strip_rows: u32, first: u32, stride: u32, out_rgba: *mut f32,

@@ -211,6 +211,18 @@ int rm_validate(rm_ctx* ctx);
  * out_max_depth (nullable) receives the deepest value-stack use of the reference machine. */
 int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, uint32_t* out_max_depth);
 
+/* Diagnostics (pure host code): what the upload-time decoder makes of a command stream.  out[0..n_out) receives, in this order
+ * (indices RM_PROGRAM_*): records, cone entries and slab entries of the miss-test tables, leaves left out of those tables
+ * because they sit in the right operand of a Subtraction, paired far-test groups, value-stack slots the accumulator machine
+ * spills, then four 0/1 facts -- chain program (stack-free interpreter loop), prunable (far-primitive pruning applies),
+ * miss test on lower bounds applies, program has space transformations.  Same status codes as rm_validate_program. */
+enum rm_program_fact {
+    RM_PROGRAM_RECORDS = 0, RM_PROGRAM_CONES = 1, RM_PROGRAM_SLABS = 2, RM_PROGRAM_SUBTRACTED_LEAVES = 3, RM_PROGRAM_GROUPS = 4,
+    RM_PROGRAM_SPILL_DEPTH = 5, RM_PROGRAM_IS_CHAIN = 6, RM_PROGRAM_PRUNABLE = 7, RM_PROGRAM_BOUND_WALK = 8, RM_PROGRAM_HAS_XFORMS = 9,
+    RM_PROGRAM_FACTS = 10
+};
+int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, uint32_t* out, uint32_t n_out);
+
 /* paint (renderer.rs:244-255) restricted to rows [row0,row0+rows) of a W x H target.
  * out_rgba receives rows*W*4 floats.  out_is_device = 0: host memory, filled on return.
  * out_is_device = 1: device memory on ctx's GPU; the launch is asynchronous on `stream`, a

@@ -95,6 +95,8 @@ def hip_lib():
         L.rm_validate.argtypes = [vp]
         L.rm_validate_program.argtypes = [u32, C.POINTER(u32), u32, C.POINTER(u32)]
         L.rm_validate_program.restype = C.c_int
+        L.rm_program_info.argtypes = [u32, C.POINTER(u32), u32, C.POINTER(u32), u32]
+        L.rm_program_info.restype = C.c_int
         L.rm_draw.argtypes = [vp, u32, u32, u32, u32, vp, C.c_int, vp]
         L.rm_draw_strips.argtypes = [vp, u32, u32, u32, u32, u32, vp, C.c_int, vp, C.POINTER(u32)]
         L.rm_draw_strips.restype = C.c_int

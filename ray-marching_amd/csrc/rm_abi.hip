@@ -758,6 +758,18 @@ RM_EXPORT int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uin
     return rc;
 }
 
+RM_EXPORT int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, uint32_t* out, uint32_t n_out) {
+    RmDecoded d;
+    int rc = rm_decode_program(cmd_count, words, n_words, &d);
+    if (rc != RM_OK) return rc;
+    uint32_t subtracted = 0u;
+    for (const RmRecord& r : d.rec) subtracted += (r.op & RM_OP_NOCULL) != 0u;
+    const uint32_t facts[RM_PROGRAM_FACTS] = {(uint32_t)d.rec.size(), d.n_sphere, d.n_box, subtracted, (uint32_t)d.groups.size(), d.spill_depth,
+                                              d.is_chain ? 1u : 0u, d.prunable ? 1u : 0u, d.bound_walk ? 1u : 0u, d.has_xforms ? 1u : 0u};
+    for (uint32_t i = 0; out && i < n_out && i < (uint32_t)RM_PROGRAM_FACTS; i++) out[i] = facts[i];
+    return RM_OK;
+}
+
 RM_EXPORT int rm_draw(rm_ctx* c, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, float* out_rgba,
                       int out_is_device, void* stream) {
     if (!c) return RM_ERR_NULL;

@@ -208,6 +208,21 @@ def validate_program(cmd_count, words):
     return rc, depth.value
 
 
+PROGRAM_FACTS = ("records", "cones", "slabs", "subtracted_leaves", "groups", "spill_depth", "is_chain", "prunable", "bound_walk",
+                 "has_xforms")
+
+
+def program_info(cmd_count, words):
+    """rm_program_info: what the upload-time decoder makes of a command stream, as a dict (pure host code, no GPU needed)."""
+    w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
+    ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
+    out = (C.c_uint32 * len(PROGRAM_FACTS))()
+    rc = _ffi.hip_lib().rm_program_info(int(cmd_count), ptr, int(w.size), out, len(PROGRAM_FACTS))
+    if rc != _ffi.RM_OK:
+        raise _ffi.RmError(rc, _ffi.hip_lib().rm_status_string(rc).decode())
+    return dict(zip(PROGRAM_FACTS, [int(v) for v in out]))
+
+
 def jit_source(cmd_count, words, waves_per_tile=4, prune=False):
     """rm_jit_source: the HIP source the structure specialiser generates for a command stream (no GPU needed)."""
     w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))

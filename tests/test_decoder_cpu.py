@@ -1,0 +1,74 @@
+"""What the upload-time decoder (ray-marching_amd/csrc/rm_decode.h) derives from a command stream, through rm_program_info:
+record fusion, the miss-test tables without the leaves a Subtraction takes away, far-test pairs, and which programs get the
+stack-free interpreter loop or the miss test on lower bounds.  Pure host code: runs without a GPU."""
+import numpy as np
+import pytest
+
+import scenes
+from ray_marching_amd import _ffi, renderer
+
+U, S, I = scenes.UNION, scenes.SUBTRACTION, scenes.INTERSECTION
+
+
+def info(oracle, nodes, root):
+    cc, w = oracle.serialize(nodes, root)
+    return renderer.program_info(cc, w)
+
+
+def test_metric_scenes(oracle):
+    g32 = info(oracle, *scenes.g32())
+    # 16 primitives in a left-deep chain, every operator fused into its right operand's record; every fourth operator is a
+    # Subtraction: its three primitives are not in the miss-test tables (max(a, -b) >= a)
+    assert g32["records"] == 16 and g32["is_chain"] == 1 and g32["prunable"] == 1 and g32["groups"] == 8
+    assert g32["subtracted_leaves"] == 3 and g32["cones"] + g32["slabs"] == 13
+    assert g32["spill_depth"] == 0 and g32["bound_walk"] == 0 and g32["has_xforms"] == 0
+    g64 = info(oracle, *scenes.g64())
+    assert g64["records"] == 32 and g64["groups"] == 16 and g64["subtracted_leaves"] == 7 and g64["cones"] + g64["slabs"] == 25
+    g8 = info(oracle, *scenes.g8())          # ((S u B) - S) u B
+    assert g8["records"] == 4 and g8["is_chain"] == 1 and g8["subtracted_leaves"] == 1 and (g8["cones"], g8["slabs"]) == (1, 2)
+    bal = info(oracle, *scenes.g32_balanced())
+    assert bal["is_chain"] == 0 and bal["prunable"] == 1 and bal["records"] == 16 + 7   # 8 fused pairs, 7 operators on sub-trees
+    assert info(oracle, *scenes.g1()) == dict(records=1, cones=1, slabs=0, subtracted_leaves=0, groups=0, spill_depth=0, is_chain=1,
+                                               prunable=1, bound_walk=0, has_xforms=0)
+
+
+def test_right_operands_of_a_subtraction_leave_the_tables(oracle):
+    t = scenes._Tab()      # a - (b u c): both leaves of the right operand
+    i = info(oracle, t.nodes, t.op(S, t.sphere((0, 0, 0), 1.0), t.op(U, t.box((1, 0, 0), (0.5, 0.5, 0.5)), t.sphere((-1, 0, 0), 0.5))))
+    assert i["subtracted_leaves"] == 2 and (i["cones"], i["slabs"]) == (1, 0)
+    t = scenes._Tab()      # a - (b - c): c counts positively in the value but is dropped as well (conservative)
+    i = info(oracle, t.nodes, t.op(S, t.box((0, 0, 0), (1, 1, 1)), t.op(S, t.sphere((0.5, 0, 0), 0.8), t.box((0.5, 0, 0), (0.3, 0.3, 0.3)))))
+    assert i["subtracted_leaves"] == 2 and (i["cones"], i["slabs"]) == (0, 1)
+    t = scenes._Tab()      # (a - b) u (c - d): the left operands stay
+    i = info(oracle, t.nodes, t.op(U, t.op(S, t.sphere((0, 0, 0), 1), t.sphere((0.5, 0, 0), 0.5)), t.op(S, t.box((3, 0, 0), (1, 1, 1)), t.sphere((3, 1, 0), 0.5))))
+    assert i["subtracted_leaves"] == 2 and (i["cones"], i["slabs"]) == (1, 1)
+    t = scenes._Tab()      # an intersection keeps both operands
+    i = info(oracle, t.nodes, t.op(I, t.sphere((0, 0, 0), 1), t.box((0, 0, 0), (0.8, 0.8, 0.8))))
+    assert i["subtracted_leaves"] == 0 and (i["cones"], i["slabs"]) == (1, 1)
+    t = scenes._Tab()      # with a transform the tables keep one cone per bounded primitive (their slots index the bounds)
+    i = info(oracle, t.nodes, t.op(S, t.sphere((0, 0, 0), 1.0), t.translation(t.sphere((0.5, 0, 0), 0.5), (0.1, 0, 0))))
+    assert i["has_xforms"] == 1 and i["subtracted_leaves"] == 0 and i["cones"] == 2
+
+
+def test_which_programs_get_the_miss_test_on_lower_bounds(oracle):
+    assert info(oracle, *scenes.EXT_SCENES["g32s"]())["bound_walk"] == 1          # BASELINE config 3: a chain of blends
+    t = scenes._Tab()
+    assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.box((1, 0, 0), (0.5, 0.5, 0.5)), 0.3))["bound_walk"] == 1
+    t = scenes._Tab()      # k <= 0: a plain min, nothing to sharpen
+    assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.box((1, 0, 0), (0.5, 0.5, 0.5)), 0.0))["bound_walk"] == 0
+    t = scenes._Tab()      # a cylinder: no closed-form bound here
+    assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.cylinder((1, 0, 0), 0.3, 0.6), 0.3))["bound_walk"] == 0
+    t = scenes._Tab()      # a balanced tree of blends spills more than one value
+    lv = [t.sphere((float(k), 0, 0), 0.4) for k in range(8)]
+    while len(lv) > 1:
+        lv = [t.smooth_union(lv[j], lv[j + 1], 0.3) for j in range(0, len(lv), 2)]
+    i = info(oracle, t.nodes, lv[0])
+    assert i["spill_depth"] >= 2 and i["bound_walk"] == 0 and i["prunable"] == 0
+    t = scenes._Tab()
+    assert info(oracle, t.nodes, t.scale(t.smooth_union(t.sphere((0, 0, 0), 1), t.sphere((1, 0, 0), 0.5), 0.3), 2.0))["bound_walk"] == 0
+
+
+def test_invalid_programs_report_the_validators_status():
+    with pytest.raises(_ffi.RmError) as e:
+        renderer.program_info(1, np.array([100], np.uint32))       # a Union with nothing on the stack
+    assert e.value.status == _ffi.RM_ERR_STACK_UNDERFLOW
