@@ -38,8 +38,8 @@ struct RmDecoded {
     // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
     bool is_chain = false;
     // The miss test of a ray can run the program on lower bounds (rm_kernel_v5.h "Miss test on lower bounds"): the program
-    // blends with SmoothUnion (otherwise the plain tests are as sharp), every leaf is a sphere or a box in world space (no
-    // transforms), and the accumulator machine never holds more than one spilled value
+    // blends with SmoothUnion or holds a Plane the tables cannot clear (otherwise the plain tests are as sharp), its leaves
+    // are in world space (no transforms), and the accumulator machine never holds more than one spilled value
     bool bound_walk = false;
     // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
     // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
@@ -279,6 +279,7 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         d.n_sphere = d.n_box = 0u;
         for (RmRecord& r : d.rec) {
             const uint32_t kind = RM_OP_KIND(r.op);
+            if (kind == RM_KIND_PLANE) continue;  // no table entry either way; a subtracted Plane (RM_OP_NOCULL) does not veto the tables
             if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX && kind != RM_KIND_CYLINDER) { r.op &= ~(uint32_t)RM_OP_NOCULL; continue; }
             uint32_t slot = 0u;
             if (!(r.op & RM_OP_NOCULL)) slot = kind == RM_KIND_SPHERE ? d.n_sphere++ : d.n_box++;
@@ -322,11 +323,10 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) != 0u;
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
-    d.bound_walk = d.smooth_slack > 0.0 && d.smooth_slack < 1.0e30 && !d.has_xforms && d.spill_depth <= 1u && d.scene_scale < 1.0e12f;
-    for (const RmRecord& r : d.rec) {
-        const uint32_t kind = RM_OP_KIND(r.op);
-        if (kind != RM_KIND_POP && kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) d.bound_walk = false;
-    }
+    bool plane_in_tables = false;  // a Plane the tables would have to clear: they cannot
+    for (const RmRecord& r : d.rec) plane_in_tables = plane_in_tables || (RM_OP_KIND(r.op) == RM_KIND_PLANE && !(r.op & RM_OP_NOCULL));
+    d.bound_walk = ((d.smooth_slack > 0.0 && d.smooth_slack < 1.0e30) || (plane_in_tables && d.smooth_slack == 0.0)) && !d.has_xforms &&
+                   d.spill_depth <= 1u && d.scene_scale < 1.0e12f;
     d.n_words = ptr;
     *out = std::move(d);
     return RM_OK;

@@ -237,7 +237,8 @@ constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 3u * 64u;
 //   slab[n_slab]  three float4 per box / cylinder: lo - o and hi - o of the bounding box inflated by
 //                 the margin, then the cone of that box's bounding sphere (a cheap pre-test: only
 //                 if some lane's ray enters that cone does the wave run the 6-multiply slab test)
-//   veto          set when anything is non-finite: then nothing is culled
+//   veto          bit 0: something is non-finite, nothing may be culled; bit 1: the program has a Plane, the tables cannot
+//                 clear a ray (the miss test on lower bounds still can)
 struct CullTables {
     const float4* cone;
     const float4* slab;
@@ -258,8 +259,8 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
                           uint32_t* veto, const float4* bounds = nullptr) {
     uint32_t kind = RM_OP_KIND(rec.op);
     if (kind == RM_KIND_POP || kind == RM_KIND_XFORM) return;
-    if (kind == RM_KIND_PLANE) { *veto = 1u; return; }  // unbounded primitive: nothing can be culled
     if (rec.op & RM_OP_NOCULL) return;  // subtracted: a hit needs the left operand's surface, whatever this one does
+    if (kind == RM_KIND_PLANE) { atomicOr(veto, 2u); return; }  // unbounded primitive: the tables cannot clear anything (bit 1)
     const float inf = __uint_as_float(0x7F800000u);
     const uint32_t slot = __float_as_uint(rec.p[6]);
     float cx = rec.p[0], cy = rec.p[1], cz = rec.p[2], sphere_r = rec.p[3];
@@ -300,7 +301,7 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
         if (lim > 0.0f && lim < inf) sv = __builtin_sqrtf(lim) * (1.0f - 1.0e-5f) - 1.0e-5f * __builtin_sqrtf(mm);
         slab[3u * slot + 2u] = make_float4(mx, my, mz, sv);
     }
-    if (!finite || !(slack < inf)) *veto = 1u;
+    if (!finite || !(slack < inf)) atomicOr(veto, 1u);  // bit 0: non-finite data, nothing may be culled by any test
 }
 
 // true iff the half-line o + t d (t >= 0) provably stays clear of every primitive's margin zone.
@@ -381,16 +382,30 @@ RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, cons
         } else {
             const float mx = p[0] - ro.x, my = p[1] - ro.y, mz = p[2] - ro.z;
             const float mm = __builtin_fmaf(mz, mz, __builtin_fmaf(my, my, mx * mx));
-            float reach;  // CONE: bounding radius of the leaf
-            if (kind == RM_KIND_SPHERE) {
+            float reach = 0.0f;  // CONE: bounding radius of the leaf
+            bool bounded = true;
+            if (kind == RM_KIND_PLANE) {
+                // dot(q, n) + h is linear along a ray: v0 + t (n.d); over t >= 0 its infimum is v0 when n.d >= 0, else -inf.
+                // CONE: every sample direction e has n.e >= n.c - |n| rho.  |n| is arbitrary (the value is not a distance): the
+                // slack scales with it.
+                const float nn = __builtin_amdgcn_sqrtf(__builtin_fmaf(p[2], p[2], __builtin_fmaf(p[1], p[1], p[0] * p[0]))) * 1.00001f;
+                const float v0 = __builtin_fmaf(p[2], ro.z, __builtin_fmaf(p[1], ro.y, p[0] * ro.x)) + p[3];
+                const float nd = __builtin_fmaf(p[2], dz, __builtin_fmaf(p[1], dy, p[0] * dx));
+                const float slope = CONE ? nd - nn * (rho * 1.00001f) : nd;
+                const float away = 1.0e-5f * nn;  // covers the rounding of n.d and of the march positions' own n.q
+                b = slope >= away ? v0 - (1.0e-5f * (__builtin_fabsf(v0) + __builtin_fabsf(p[3])) + nn * (4.0f * lower)) : -inf;
+                bounded = false;
+            } else if (kind == RM_KIND_SPHERE) {
                 const float cx = __builtin_fmaf(my, dz, -(mz * dy)), cy = __builtin_fmaf(mz, dx, -(mx * dz)), cz = __builtin_fmaf(mx, dy, -(my * dx));
                 const float perp2 = __builtin_fmaf(cz, cz, __builtin_fmaf(cy, cy, cx * cx));
                 reach = fmax_(p[3], 0.0f);
                 const float along = __builtin_fmaf(mz, dz, __builtin_fmaf(my, dy, mx * dx));
                 const float dist = __builtin_amdgcn_sqrtf(along > 0.0f ? perp2 : mm);
                 b = dist * (1.0f - 1.0e-5f) - p[3];
-            } else {  // RM_KIND_BOX
-                const float hx = fmax_(p[3], 0.0f), hy = fmax_(p[4], 0.0f), hz = fmax_(p[5], 0.0f);
+            } else {  // RM_KIND_BOX; RM_KIND_CYLINDER through its bounding box (radius, half height, radius): a solid inside
+                      // another is at least as far as that one
+                const bool cyl = kind == RM_KIND_CYLINDER;
+                const float hx = fmax_(p[3], 0.0f), hy = fmax_(p[4], 0.0f), hz = cyl ? hx : fmax_(p[5], 0.0f);
                 reach = (hx + hy) + hz;  // >= |h|
                 const float x1 = (mx - hx) * ix, x2 = (mx + hx) * ix, y1 = (my - hy) * iy, y2 = (my + hy) * iy;
                 const float z1 = (mz - hz) * iz, z2 = (mz + hz) * iz;
@@ -405,7 +420,7 @@ RM_DEV bool ray_misses_by_bounds_v5(const LoadRecord& load, uint32_t n_rec, cons
                 const float delta = fmax_(fmax_(d0, d1), fmax_(d2, d3));
                 b = delta * (1.0f - 1.0e-5f);
             }
-            if (CONE) b = b - (rho * 1.00001f) * ((__builtin_amdgcn_sqrtf(mm) * 1.00001f + reach) + fmax_(b, 0.0f));
+            if (CONE && bounded) b = b - (rho * 1.00001f) * ((__builtin_amdgcn_sqrtf(mm) * 1.00001f + reach) + fmax_(b, 0.0f));
             b = fmax_(b - (lower + 1.0e-5f * __builtin_fabsf(b)), -3.0e38f);  // NaN -> -3e38
             if (op & RM_OP_SPILL) spilled = acc;
             a = acc;
@@ -637,7 +652,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
                                       ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
 #if !defined(RM_JIT_TU) || defined(RM_JIT_BOUND_WALK)  // a generated kernel carries it only if its program's structure can use it
-                        if ((L.flags & 32u) && *s_veto == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
+                        if ((L.flags & 32u) && (*s_veto & 1u) == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
                             culled = culled || ray_misses_by_bounds_v5<false>(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
 #endif
                         if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
@@ -933,11 +948,12 @@ RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const 
     const float rho = __builtin_sqrtf(rho2) * 1.001f + 2.0e-6f;
     // NaN anywhere above (zero / non-finite directions) makes this false; v_max drops a NaN operand, so
     // the corners are checked one by one as well
-    bool clear = *T.veto == 0u && rho < 0.05f;
+    bool cone_ok = rho < 0.05f;
 #pragma unroll
-    for (uint32_t c = 0; c < 4u; c++) clear = clear && (ex[c] - cx) * (ex[c] - cx) < 1.0f && (ey[c] - cy) * (ey[c] - cy) < 1.0f && (ez[c] - cz) * (ez[c] - cz) < 1.0f;
+    for (uint32_t c = 0; c < 4u; c++) cone_ok = cone_ok && (ex[c] - cx) * (ex[c] - cx) < 1.0f && (ey[c] - cy) * (ey[c] - cy) < 1.0f && (ez[c] - cz) * (ez[c] - cz) < 1.0f;
     cone_out[0] = cx; cone_out[1] = cy; cone_out[2] = cz;
-    cone_out[3] = clear ? rho : __uint_as_float(0x7FC00000u);  // (clear so far: the cone itself is valid)
+    cone_out[3] = cone_ok ? rho : __uint_as_float(0x7FC00000u);
+    bool clear = cone_ok && *T.veto == 0u;  // a Plane (veto bit 1) leaves the tables unusable, not the cone
     for (uint32_t k = 0; k < T.n_cone; k++) {
         const float4 a = T.cone[k];  // wave-uniform address: LDS broadcast
         const float t = __builtin_fmaf(aux[k].x, rho, __builtin_fmaf(a.z, cz, __builtin_fmaf(a.y, cy, a.x * cx)));
@@ -1022,7 +1038,7 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
         // a program that blends: the pixels the inflated bounds could not clear get the program run on lower bounds of its
         // leaves over the pixel's cone ("Miss test on lower bounds"; the march kernel repeats it per ray for what is left)
         const float bound_scale = (L.scene_scale + L.smooth_slack) + ((__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y)) + __builtin_fabsf(ro.z));
-        if ((L.flags & 32u) && *s_veto == 0u && bound_scale < 1.0e12f && __ballot(!clear && cone[3] == cone[3]) != 0ull) {
+        if ((L.flags & 32u) && (*s_veto & 1u) == 0u && bound_scale < 1.0e12f && __ballot(!clear && cone[3] == cone[3]) != 0ull) {
             auto load_record = [&](uint32_t i, uint32_t& op, float (&p)[7]) {
                 const RmRecord& r = L.prog[i];  // wave-uniform address: scalar loads
                 op = r.op;

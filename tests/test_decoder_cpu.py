@@ -56,8 +56,14 @@ def test_which_programs_get_the_miss_test_on_lower_bounds(oracle):
     assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.box((1, 0, 0), (0.5, 0.5, 0.5)), 0.3))["bound_walk"] == 1
     t = scenes._Tab()      # k <= 0: a plain min, nothing to sharpen
     assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.box((1, 0, 0), (0.5, 0.5, 0.5)), 0.0))["bound_walk"] == 0
-    t = scenes._Tab()      # a cylinder: no closed-form bound here
-    assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.cylinder((1, 0, 0), 0.3, 0.6), 0.3))["bound_walk"] == 0
+    t = scenes._Tab()      # a cylinder is bounded through its bounding box
+    assert info(oracle, t.nodes, t.smooth_union(t.sphere((0, 0, 0), 1), t.cylinder((1, 0, 0), 0.3, 0.6), 0.3))["bound_walk"] == 1
+    t = scenes._Tab()      # a Plane: the tables cannot clear anything, the bound walk can (rays that point away from it)
+    i = info(oracle, t.nodes, t.op(U, t.sphere((0, 0, 0), 1), t.plane((0.0, 1.0, 0.0), 1.5)))
+    assert i["bound_walk"] == 1 and (i["cones"], i["slabs"]) == (1, 0)
+    t = scenes._Tab()      # ... unless a Subtraction takes the Plane out of the tables anyway
+    i = info(oracle, t.nodes, t.op(S, t.sphere((0, 0, 0), 1), t.plane((0.0, 1.0, 0.0), 0.2)))
+    assert i["bound_walk"] == 0 and i["subtracted_leaves"] == 1
     t = scenes._Tab()      # a balanced tree of blends spills more than one value
     lv = [t.sphere((float(k), 0, 0), 0.4) for k in range(8)]
     while len(lv) > 1:

@@ -1,7 +1,8 @@
 """Differential test of the miss tests: the same frame with culling on and with culling off must be the same bytes (culling off
 marches every ray, which is what the oracle does; the oracle comparison itself is in test_gpu_parity.py / test_gpu_fuzz.py).  GPU
 against GPU, so it can afford what the oracle cannot: larger frames, hundreds of random programs and cameras.  The programs are
-left-deep chains of spheres and boxes under SmoothUnion / Union / Subtraction / Intersection -- the shapes the structure-aware
+left-deep chains of spheres and boxes (in two programs of five also cylinders and planes) under SmoothUnion / Union /
+Subtraction / Intersection -- the shapes the structure-aware
 tests act on (subtracted primitives out of the tables, the program run on lower bounds) -- plus right operands that are
 sub-trees.  RM_CULL_SEEDS=N runs N programs (default 40)."""
 import os
@@ -17,8 +18,13 @@ pytestmark = pytest.mark.gpu
 N = int(os.environ.get("RM_CULL_SEEDS", "40"))
 
 
-def random_leaf(rng, t, spread):
+def random_leaf(rng, t, spread, extended=False):
     c = rng.uniform(-spread, spread, 3)
+    if extended and rng.random() < 0.25:
+        if rng.random() < 0.5:
+            return t.cylinder(tuple(c), float(rng.uniform(0.1, 0.5)), float(rng.uniform(0.1, 0.8)))
+        n = rng.normal(size=3) * rng.choice([1.0, 0.3, 2.5])          # |n| need not be 1
+        return t.plane(tuple(n), float(rng.uniform(0.3, 2.5)))
     if rng.random() < 0.5:
         return t.sphere(tuple(c), float(rng.choice([rng.uniform(0.15, 0.7), 0.0, -0.2], p=[0.9, 0.05, 0.05])))
     h = rng.uniform(0.08, 0.7, 3)
@@ -31,12 +37,13 @@ def random_program(rng):
     t = scenes._Tab()
     spread = float(rng.choice([1.0, 1.8, 3.0]))
     blend = rng.random() < 0.7
+    extended = rng.random() < 0.4       # cylinders and planes among the leaves
     acc = random_leaf(rng, t, spread)
     for _ in range(int(rng.integers(1, 18))):
         if rng.random() < 0.15:     # a sub-tree as right operand
-            right = t.op(scenes.UNION if rng.random() < 0.6 else scenes.SUBTRACTION, random_leaf(rng, t, spread), random_leaf(rng, t, spread))
+            right = t.op(scenes.UNION if rng.random() < 0.6 else scenes.SUBTRACTION, random_leaf(rng, t, spread, extended), random_leaf(rng, t, spread, extended))
         else:
-            right = random_leaf(rng, t, spread)
+            right = random_leaf(rng, t, spread, extended)
         r = rng.random()
         if blend and r < 0.5:
             acc = t.smooth_union(acc, right, float(rng.choice([rng.uniform(0.02, 1.0), 0.0, -0.3], p=[0.9, 0.05, 0.05])))

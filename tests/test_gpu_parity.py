@@ -839,8 +839,9 @@ def test_miss_test_on_lower_bounds_is_exact(res, oracle, kernel):
     the program run on lower bounds of its leaves along the ray (rm_kernel_v5.h "Miss test on lower bounds").  Random
     chains of spheres and boxes joined by SmoothUnion / Union / Subtraction / Intersection -- k small, large, zero,
     negative; flat, degenerate and negative sizes; everything 1000 units from the origin -- from eight cameras (inside a
-    solid, grazing, top-down, far): culling on == culling off == oracle.  A balanced tree of blends (needs a deeper value
-    stack) and a blended cylinder keep the plain tests and must still be right."""
+    solid, grazing, top-down, far): culling on == culling off == oracle.  Cylinders (through their bounding box) and Planes
+    (linear along a ray: bounded exactly when the ray points away) take part; a balanced tree of blends (needs a deeper
+    value stack) keeps the plain tests and must still be right."""
     rng = np.random.default_rng(2024)
     W, H = 64, 40
     lim = (0.01, 100.0, 80)
@@ -880,9 +881,17 @@ def test_miss_test_on_lower_bounds_is_exact(res, oracle, kernel):
     while len(level) > 1:
         level = [t.smooth_union(level[i], level[i + 1], 0.3) for i in range(0, len(level), 2)]
     programs.append(("balanced_blends", (0.0, 0.0, 0.0), (t.nodes, level[0])))
-    t = scenes._Tab()
+    t = scenes._Tab()    # a cylinder is bounded through its bounding box
     programs.append(("blended_cylinder", (0.0, 0.0, 0.0),
                      (t.nodes, t.smooth_union(t.sphere((-0.5, 0, 0), 0.6), t.cylinder((0.6, 0.0, 0.1), 0.4, 0.7), 0.3))))
+    t = scenes._Tab()    # a ground Plane (|n| = 2: the value is not a distance) under two solids: rays that point away from it
+    ground = t.plane((0.0, 2.0, 0.0), 2.4)
+    programs.append(("solids_on_a_plane", (0.0, 0.0, 0.0),
+                     (t.nodes, t.op(scenes.UNION, t.op(scenes.UNION, t.sphere((-0.7, 0.0, 0.0), 0.8), t.box((0.9, -0.4, 0.2), (0.5, 0.8, 0.5))), ground))))
+    t = scenes._Tab()    # a solid cut by a tilted Plane (Intersection), blended with a sphere
+    cutter = t.plane((0.3, 1.0, -0.2), 0.1)
+    programs.append(("plane_cut_blend", (0.0, 0.0, 0.0),
+                     (t.nodes, t.smooth_union(t.op(scenes.INTERSECTION, t.box((0, 0, 0), (1.0, 0.8, 0.9)), cutter), t.sphere((1.3, 0.4, 0.0), 0.5), 0.3))))
     for name, target, (nodes, root) in programs:
         cc, w = oracle.serialize(nodes, root)
         for cam in sorted(CULL_CAMERAS):
