@@ -271,10 +271,14 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
     // Table slots of the primitives the miss tests have to clear.  A program with transforms keeps one cone per bounded
     // primitive (their slots index `bounds`, filled above); otherwise subtracted primitives get none (RM_OP_NOCULL).
     static const bool keep_subtracted = std::getenv("RM_CULL_SUBTRACTED") && std::atoi(std::getenv("RM_CULL_SUBTRACTED")) == 0;  // A/B
-    if (d.has_xforms || keep_subtracted) {
+    if (keep_subtracted) {
         for (RmRecord& r : d.rec) r.op &= ~(uint32_t)RM_OP_NOCULL;
     }
-    if (d.has_xforms) {
+    if (d.has_xforms) {  // every bounded primitive keeps its cone slot (it indexes `bounds`); a subtracted one gets a cone no ray meets
+        for (RmRecord& r : d.rec) {
+            const uint32_t kind = RM_OP_KIND(r.op);
+            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX && kind != RM_KIND_CYLINDER && kind != RM_KIND_PLANE) r.op &= ~(uint32_t)RM_OP_NOCULL;
+        }
     } else {
         d.n_sphere = d.n_box = 0u;
         for (RmRecord& r : d.rec) {

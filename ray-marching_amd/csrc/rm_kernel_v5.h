@@ -259,7 +259,11 @@ RM_DEV void cull_build_v5(const RmRecord& rec, const V4& ro, float min_dist, flo
                           uint32_t* veto, const float4* bounds = nullptr) {
     uint32_t kind = RM_OP_KIND(rec.op);
     if (kind == RM_KIND_POP || kind == RM_KIND_XFORM) return;
-    if (rec.op & RM_OP_NOCULL) return;  // subtracted: a hit needs the left operand's surface, whatever this one does
+    if (rec.op & RM_OP_NOCULL) {  // subtracted: a hit needs the left operand's surface, whatever this one does
+        // (a program with transforms keeps a cone slot per bounded primitive: this one's clears every ray and every pixel)
+        if (bounds && kind != RM_KIND_PLANE) cone[__float_as_uint(rec.p[6])] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+        return;
+    }
     if (kind == RM_KIND_PLANE) { atomicOr(veto, 2u); return; }  // unbounded primitive: the tables cannot clear anything (bit 1)
     const float inf = __uint_as_float(0x7F800000u);
     const uint32_t slot = __float_as_uint(rec.p[6]);

@@ -936,8 +936,15 @@ def test_subtracted_primitives_leave_the_miss_tests(res, oracle, kernel):
     cases["union_of_carved"] = (t.nodes, t.op(U, t.sphere((-1.4, 0, 0), 0.6), t.op(S, t.box((0.8, 0, 0), (0.7, 0.7, 0.7)), t.box((1.6, 0.5, 0), (0.9, 0.3, 0.3)))))
     t = scenes._Tab()   # intersection with a carved operand
     cases["intersection_of_carved"] = (t.nodes, t.op(I, t.sphere((0, 0, 0), 1.1), t.op(S, t.box((0, 0, 0), (0.9, 0.9, 0.9)), t.sphere((0, 1.0, 0), 0.6))))
+    t = scenes._Tab()   # inside transform scopes (the tables then hold world-space bounding spheres: the subtracted one's clears everything)
+    hq = 0.70710678
+    carved = t.op(S, t.box((0, 0, 0), (0.9, 0.6, 0.7)), t.sphere((0.7, 0.5, 0.0), 0.6))
+    cases["carved_in_transforms"] = (t.nodes, t.op(S, t.op(U, t.translation(t.rotation(carved, (hq, 0, hq, 0)), (-0.8, 0.2, 0.1)),
+                                                          t.scale(t.sphere((1.2, 0, 0), 0.5), 1.4)),
+                                                   t.translation(t.box((0, 0, 0), (0.4, 0.4, 0.4)), (2.6, 1.2, -0.5))))
     cases["g32"] = scenes.g32()
     cases["g8"] = scenes.g8()
+    cases["xform_mix"] = scenes.EXT_SCENES["xform_mix"]()
     for name, (nodes, root) in cases.items():
         cc, w = oracle.serialize(nodes, root)
         for cam in sorted(CULL_CAMERAS):
