@@ -38,7 +38,8 @@ struct RmDecoded {
     // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
     bool is_chain = false;
     // The miss test of a ray can run the program on lower bounds (rm_kernel_v5.h "Miss test on lower bounds"): the program
-    // blends with SmoothUnion or holds a Plane the tables cannot clear (otherwise the plain tests are as sharp), its leaves
+    // blends with SmoothUnion, holds a Plane the tables cannot clear, or an Intersection (otherwise the plain tests are as
+    // sharp), its leaves
     // are in world space (no transforms), and the accumulator machine never holds more than one spilled value
     bool bound_walk = false;
     // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
@@ -327,9 +328,12 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) != 0u;
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
-    bool plane_in_tables = false;  // a Plane the tables would have to clear: they cannot
-    for (const RmRecord& r : d.rec) plane_in_tables = plane_in_tables || (RM_OP_KIND(r.op) == RM_KIND_PLANE && !(r.op & RM_OP_NOCULL));
-    d.bound_walk = ((d.smooth_slack > 0.0 && d.smooth_slack < 1.0e30) || (plane_in_tables && d.smooth_slack == 0.0)) && !d.has_xforms &&
+    // (a Plane the tables would have to clear: they cannot; an Intersection: they ask a ray to clear BOTH operands where
+    // clearing one is enough)
+    bool sharper = false;
+    for (const RmRecord& r : d.rec)
+        sharper = sharper || (RM_OP_KIND(r.op) == RM_KIND_PLANE && !(r.op & RM_OP_NOCULL)) || RM_OP_MODE(r.op) == RM_MODE_INTER;
+    d.bound_walk = ((d.smooth_slack > 0.0 && d.smooth_slack < 1.0e30) || (sharper && d.smooth_slack == 0.0)) && !d.has_xforms &&
                    d.spill_depth <= 1u && d.scene_scale < 1.0e12f;
     d.n_words = ptr;
     *out = std::move(d);

@@ -568,7 +568,7 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
     for (const RmRecord& r : rec) {
         const uint32_t kind = RM_OP_KIND(r.op);
         if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL) return false;
-        smooth = smooth || RM_OP_MODE(r.op) == RM_MODE_SMOOTH || kind == RM_KIND_PLANE;
+        smooth = smooth || RM_OP_MODE(r.op) == RM_MODE_SMOOTH || RM_OP_MODE(r.op) == RM_MODE_INTER || kind == RM_KIND_PLANE;
         if (kind == RM_KIND_POP) spilled--;
         else if (r.op & RM_OP_SPILL) spilled++;
         depth = spilled > depth ? spilled : depth;
