@@ -600,6 +600,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     if (tid == 0u) {
         *s_tile = atomicAdd(&counters[1], 1u);
         *s_next = 0u;
+        s_next[3] = 0u;  // "the per-ray miss tests clear nothing in this tile", see the production of rays below
     }
     __syncthreads();
     const uint32_t slot = *s_tile;
@@ -653,12 +654,17 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         float gx, gy, gz;
                         gen_ray_at(u.inv_proj, u.inv_view, ro, my_sx, my_sy, s_off[2u * s], s_off[2u * s + 1u], gx, gy, gz);
                         const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
-                        bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) ||
-                                      ((L.flags & 1u) && ray_misses_scene_v5(cullt, gx, gy, gz));
+                        // The miss tests are optional (a ray they do not clear is marched and ends as the same miss): in a tile
+                        // the scene covers completely they clear nothing -- 92 % of the rays that reach this kernel are marched --
+                        // so once a batch of 64 rays (one sample of every pixel of the tile) went through without a single ray
+                        // cleared, the rest of the tile's batches skip them.
+                        const bool test_rays = (L.flags & 1u) != 0u && __builtin_amdgcn_readfirstlane(s_next[3]) == 0u;
+                        bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) || (test_rays && ray_misses_scene_v5(cullt, gx, gy, gz));
 #if !defined(RM_JIT_TU) || defined(RM_JIT_BOUND_WALK)  // a generated kernel carries it only if its program's structure can use it
-                        if ((L.flags & 32u) && (*s_veto & 1u) == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
+                        if (test_rays && (L.flags & 32u) && (*s_veto & 1u) == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
                             culled = culled || ray_misses_by_bounds_v5<false>(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
 #endif
+                        if (test_rays && __ballot(culled) == 0ull && lane == 0u) s_next[3] = 1u;
                         if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                         const unsigned long long keep = __ballot(!culled);
                         if (!culled) {
