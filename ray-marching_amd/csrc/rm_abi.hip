@@ -418,7 +418,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         hipError_t e = hipModuleLaunchKernel(spec_fn, grid.x, grid.y, grid.z, 64u * WPT, 1, 1, (unsigned)shmem, s, args, nullptr);
         if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "launch of the specialised kernel failed: %s", hipGetErrorString(e));
     } else if (lds && !ext)
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     else if (lds)
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
     else if (!ext)

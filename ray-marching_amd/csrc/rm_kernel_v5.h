@@ -910,6 +910,14 @@ template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT>
 __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
     rm_render_v5_body<Prog, PROG_IN_LDS, WPT, EXT, false, EXT>(L, work, n_tiles, refill_min);
 }
+// The interpreter for reference-only programs staged in LDS -- north_star's design, and what runs while a structure compiles --
+// with its vector registers capped at 80 (6 waves per SIMD, which is also what its LDS footprint allows): left alone the
+// allocator takes 81 and a sixth of the occupancy (march kernel of the metric frame 0.83 -> 0.87 ms).
+template <int WPT>
+__global__ __launch_bounds__(64 * WPT) __attribute__((amdgpu_waves_per_eu(6, 8)))
+void rm_render_v5_lean(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
+    rm_render_v5_body<ProgLds, true, WPT, false, false, false>(L, work, n_tiles, refill_min);
+}
 
 // ---------------------------------------------------------------------------------------------
 // Pre-pass: one WAVE per tile, lane = pixel, four tiles per workgroup.
