@@ -21,6 +21,7 @@ it already runs under a launcher (WORLD_SIZE set, e.g. torch.distributed.run).  
 JSON line.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -239,6 +240,8 @@ def run_rank(args):
         for c in ctxs[:n_ctx]:
             c.set_option(_ffi.RM_OPT_TIMING, 1)     # library-side HIP events around the march kernel itself
         sync_all()
+        gc_was_on = gc.isenabled()
+        gc.disable()                                 # a collection in the middle of 12 ms of timed steps would be a large share of them
         t0 = time.perf_counter()
         for k in range(K):
             i = k % n_ctx
@@ -254,6 +257,8 @@ def run_rank(args):
         if world > 1:
             dist.barrier()
         seconds = time.perf_counter() - t0
+        if gc_was_on:
+            gc.enable()
         per_draw = sum(a.elapsed_time(b) for a, b in ev) / max(1, K)
         kms = [c.info(_ffi.RM_INFO_KERNEL_MS) for c in ctxs[:n_ctx]]
         for c in ctxs[:n_ctx]:
