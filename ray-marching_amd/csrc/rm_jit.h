@@ -157,6 +157,7 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
     // and a branch to save five).  Measured (RM_JIT_LEAF_TESTS: 1 both / 0 neither / 2 boxes = default / 3 spheres), march
     // kernel of the metric frame 0.780 / 0.780 / 0.761 / 0.784 ms, G64 at 4K 7.38 / 7.46 / 7.31 / 7.47 ms.
     const int leaf_tests = jit_knob("RM_JIT_LEAF_TESTS", 2);
+    const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0;  // A/B: the local test of subtracted leaves (below)
     for (const RmRecord& r : rec) n_pruned_total += prune && (RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX);
     std::vector<int> stack;  // value numbers; back() is the accumulator
     std::vector<int> pos;    // position numbers of the open transform scopes; back() is the current one (0 = qx, qy, qz)
@@ -242,8 +243,21 @@ inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std
             }
             const char* tested = count_mode == 2 ? "n_eval += 1u; " : "";
             const bool paired = (ordinal | 1) < n_pruned_total;
-            const bool own_test = !paired || leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
-            if (!own_test) {  // a member of a near pair is evaluated without a test of its own
+            bool own_test = !paired || leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
+            // A SUBTRACTED leaf changes max(acc, -v) only where -v > acc: at a position outside it (v > 0) with acc >= 0 -- a ray
+            // that is not inside anything -- never.  That is a test on values at hand (the squared distance, the accumulator),
+            // sharper than the threshold test it replaces wherever acc >= 0, and exact without any Lipschitz argument.
+            const bool local_sub = mode == RM_MODE_SUB && sub_tests;
+            if (local_sub) {
+                own_test = true;
+                if (kind == RM_KIND_SPHERE) {
+                    std::snprintf(line, sizeof line, "    { %sconst float a = spec_sphere_a(lp + %u, %s);\n      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) ", tested, off, P, off, a);
+                    std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
+                } else {
+                    std::snprintf(line, sizeof line, "    { %sconst SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_sub_box_near(live, b.a, v%d)) ", tested, off, P, a);
+                    std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
+                }
+            } else if (!own_test) {  // a member of a near pair is evaluated without a test of its own
                 std::snprintf(leaf, sizeof leaf, "%s<FAST>(lp + %u, %s, tiny)", kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, P);
                 std::snprintf(line, sizeof line, "    %s", tested);
             } else if (kind == RM_KIND_SPHERE) {

@@ -138,6 +138,17 @@ RM_DEV uint32_t spec_group_near_lanes(unsigned long long live, LdsF r, float qx,
     const float t = thrk + p.w;
     return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!(a > t * t)) & live);
 }
+// Subtracted leaves (mode SUB fused into the leaf): max(acc, -v) = acc whenever -v <= acc, in particular at every position
+// OUTSIDE the leaf (v > 0) while acc >= 0.  Sphere: a > (r k)^2 (r k: RmRecord::p[4], k = 1.000005) puts sqrt(a) above r by
+// more than its rounding, so the computed v = sqrt(a) - r is > 0; NaN fails the comparison and the leaf is evaluated.
+RM_DEV bool spec_sub_sphere_near(unsigned long long live, LdsF r, float a, float acc) {
+    const float rk = r[4];
+    return ((__builtin_amdgcn_ballot_w64(!(a > rk * rk)) | __builtin_amdgcn_ballot_w64(!(acc >= 0.0f))) & live) != 0ull;
+}
+// Box: a = |max(q, 0)|^2 > 0 means some q_i > 0: the inside term is +0 and v = sqrt(a) > 0.
+RM_DEV bool spec_sub_box_near(unsigned long long live, float a, float acc) {
+    return ((__builtin_amdgcn_ballot_w64(!(a > 0.0f)) | __builtin_amdgcn_ballot_w64(!(acc >= 0.0f))) & live) != 0ull;
+}
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
     const lds_f4 c = lds_load4(r);       // cx cy cz rx
@@ -476,6 +487,9 @@ RM_DEV bool lane_of(unsigned long long m, uint32_t lane) {
     (void)lane;
     return r != 0u;
 }
+
+struct TrueTag { static constexpr bool value = true; };
+struct FalseTag { static constexpr bool value = false; };
 
 // Persistent workgroups: the grid holds about as many workgroups as the chip has room for; each
 // takes the next tile of the work list with one atomic and leaves when the list is exhausted
@@ -865,29 +879,39 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     for (uint32_t p = tid; p < 64u; p += 64u * WPT) {
         const uint32_t px = tile_x * 8u + (p & 7u), py = tile_y * 8u + (p >> 3);
         if (px < L.W && py < L.rows) {
-            float tr = 0.0f, tg = 0.0f, tb = 0.0f;
+            // the 48 gamma square roots of a pixel (wgsl:68) take the short form of the leaves' sqrt (rm_interp.h sqrt_rn_fast:
+            // the same bits for every argument its guard lets through); a colour it does not -- negative, NaN, infinite: only a
+            // material table can produce one -- sends the pixel through the generic form
+            auto sum_samples = [&](auto fast_tag, float& tr, float& tg, float& tb, SqrtGuard& guard) {
+                constexpr bool FAST = decltype(fast_tag)::value;
+                tr = 0.0f; tg = 0.0f; tb = 0.0f;
 #pragma unroll 4
-            for (uint32_t s = 0; s < 16u; s++) {
-                const float code = res[s * 64u + p];
-                float cr, cg, cb;
-                if (code >= 0.0f) {  // hit: (0.4,0.7,0.1) * k  (wgsl:105)
-                    cr = 0.4f * code; cg = 0.7f * code; cb = 0.1f * code;
-                    if constexpr (MAT) {
-                        if (tagged) {  // extension: the albedo of the material the surface carries
-                            const float4 al = L.materials[rmat[s * 64u + p]];
-                            cr = al.x * code; cg = al.y * code; cb = al.z * code;
+                for (uint32_t s = 0; s < 16u; s++) {
+                    const float code = res[s * 64u + p];
+                    float cr, cg, cb;
+                    if (code >= 0.0f) {  // hit: (0.4,0.7,0.1) * k  (wgsl:105)
+                        cr = 0.4f * code; cg = 0.7f * code; cb = 0.1f * code;
+                        if constexpr (MAT) {
+                            if (tagged) {  // extension: the albedo of the material the surface carries
+                                const float4 al = L.materials[rmat[s * 64u + p]];
+                                cr = al.x * code; cg = al.y * code; cb = al.z * code;
+                            }
                         }
+                    } else if (code > -2.5f) {  // floor (wgsl:127)
+                        const float g = 0.2f * (-1.0f - code);
+                        cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
+                    } else {
+                        cr = 0.0f; cg = 0.0f; cb = 0.0f;  // wgsl:130
                     }
-                } else if (code > -2.5f) {  // floor (wgsl:127)
-                    const float g = 0.2f * (-1.0f - code);
-                    cr = 0.1f + g; cg = 0.1f + g; cb = 0.2f + g;
-                } else {
-                    cr = 0.0f; cg = 0.0f; cb = 0.0f;  // wgsl:130
+                    tr += sqrt_sel<FAST, true>(cr, guard);
+                    tg += sqrt_sel<FAST, true>(cg, guard);
+                    tb += sqrt_sel<FAST, true>(cb, guard);
                 }
-                tr += __builtin_sqrtf(cr);
-                tg += __builtin_sqrtf(cg);
-                tb += __builtin_sqrtf(cb);
-            }
+            };
+            float tr, tg, tb;
+            SqrtGuard gamma_guard;
+            sum_samples(TrueTag(), tr, tg, tb, gamma_guard);
+            if (gamma_guard.bad()) sum_samples(FalseTag(), tr, tg, tb, gamma_guard);  // per lane: the rare pixel, not the wave
             store_pixel(L, blockIdx.z, (size_t)py * L.W + px, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75
         }
     }

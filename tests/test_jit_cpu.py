@@ -51,7 +51,9 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
         "float v2 = v1;",
         "if (g1)",
-        "{ v2 = vmax_negb(v1, spec_sphere<FAST>(lp + 16, x0, y0, z0, tiny)); }",
+        # a SUBTRACTED leaf: evaluated only if some live lane is inside it, or inside the accumulated solid (max(acc, -v) = acc else)
+        "{ const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
+        "if (spec_sub_sphere_near(live, lp + 16, a, v1)) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny)); } }",
         "float v3 = v2;",
         "if (g1)",
         "{ const SpecBox b = spec_box_a(lp + 24, x0, y0, z0);",
@@ -96,7 +98,7 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
             rec = int(m.group(1)) // 8
             pending = sphere(rec) if "sphere" in line else box(rec)
             continue
-        m = re.match(r"if \(spec_any_near\(.*?\)\) \{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \} \}", line)
+        m = re.match(r"if \(spec_(?:any_near|sub_sphere_near|sub_box_near)\(.*?\)\) \{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \} \}", line)
         if m:
             tgt, op, acc = m.groups()
             if not (prune_all_far and prune_all_far(pending)):
