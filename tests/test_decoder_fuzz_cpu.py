@@ -1,0 +1,29 @@
+"""The upload-time decoder (ray-marching_amd/csrc/rm_decode.h) under AddressSanitizer + UndefinedBehaviorSanitizer: it is the one
+place where bytes from the host application are interpreted.  tests/cpp/decode_fuzz.cpp feeds it well-formed random programs
+(every node type, transform scopes, material tags, NaN / inf parameters), the same with words flipped, tails cut and command
+counts off by a few, and pure noise; every stream must be rejected with a status or decode into records that satisfy the
+invariants the kernels rely on (table slots within their tables, flags only where they mean something, depths within the
+machine's limits).  CPU only: GPU sanitizers are not available on this pool."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_decoder_survives_random_and_damaged_programs(tmp_path):
+    cxx = os.environ.get("CXX", "g++")
+    if not shutil.which(cxx):
+        pytest.skip("no C++ compiler")
+    exe = tmp_path / "decode_fuzz"
+    build = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                            "-I", os.path.join(ROOT, "ray-marching_amd", "csrc"), "-o", str(exe),
+                            os.path.join(ROOT, "tests", "cpp", "decode_fuzz.cpp")], capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe), "30000"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "decoder fuzz ok" in run.stdout
