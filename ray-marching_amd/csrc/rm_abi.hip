@@ -362,6 +362,10 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // program run on lower bounds of its leaves along the ray.  RM_BOUND_WALK=0 (diagnostics) keeps the plain tests only.
     static const bool bound_walk_on = !(std::getenv("RM_BOUND_WALK") && std::atoi(std::getenv("RM_BOUND_WALK")) == 0);
     if (cull && c->decoded.bound_walk && bound_walk_on) L.flags |= 32u;
+    // diagnostics: RM_PRE_NEED_MAX=n, the largest number of pixels of a clear tile the pre-pass finishes sample-parallel (default 24;
+    // 0: only tiles that need none, 64: always)
+    static const int pre_need_max = std::getenv("RM_PRE_NEED_MAX") ? std::atoi(std::getenv("RM_PRE_NEED_MAX")) : -1;
+    if (pre_need_max >= 0 && pre_need_max <= 64) L.flags |= (uint32_t)(pre_need_max + 1) << 8;
     const uint32_t n_tiles = ((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u);
     if (!cull) L.n_cone = L.n_slab = 0u;
     const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;
@@ -380,7 +384,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
     if (int rc = ensure_tile_buffers(c, (size_t)n_tiles * n_frames)) return rc;
     if (int rc = grow_device(c, &c->d_counters, &c->d_counters_cap, (size_t)n_frames * 4u)) return rc;
-    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + rmk::V5_PRE_TILES - 1u) / rmk::V5_PRE_TILES, 1, n_frames),
+    const uint32_t pre_tiles_per_group = rmk::V5_PRE_TILES * rmk::V5_PRE_TILES_PER_WAVE;
+    hipLaunchKernelGGL(rmk::rm_tile_pre_v5, dim3((n_tiles + pre_tiles_per_group - 1u) / pre_tiles_per_group, 1, n_frames),
                        dim3(64u * rmk::V5_PRE_TILES), 16u + cull_bytes + (size_t)(L.n_cone + L.n_slab) * 8u, s, L, c->d_cost, n_tiles);
     // RM_OPT_BALANCE = 3: the march kernel records how long every tile took; the next draw of the same shape
     // dispatches the longest first (consecutive frames of an interactive view or an orbit look alike)

@@ -967,16 +967,24 @@ void rm_render_v5_lean(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refil
 // (wgsl:44-45, 68-69, 73-75) and writes it.  Tiles with cost > 0 go on the work list; the march
 // kernel repeats the (sharper) test per ray.  ~60 % of the tiles of the metric frame end here.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t V5_PRE_TILES = 4u;  // tiles (= waves) per pre-pass workgroup
+constexpr uint32_t V5_PRE_TILES = 4u;  // waves per pre-pass workgroup, one tile at a time each
+// Tiles each of those waves walks through: one.  (Four -- to spread the workgroup's prologue: records fetched, tables built, three
+// barriers -- made the kernel slower, 60 -> 75 us: it is bound by its work, and expensive tiles are neighbours.)
+constexpr uint32_t V5_PRE_TILES_PER_WAVE = 1u;
 
 #if !defined(RM_JIT_TU)  // not part of a specialised translation unit (rm_jit.h)
-// cone_out: (unit centre direction, rho) of the pixel's sixteen sample directions; rho = NaN when the cone is not usable
-RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const rm_uniforms& u, const V4& ro, float sx,
-                                  float sy, float (&cone_out)[4]) {
+// cone_out: (unit centre direction, rho) of the pixel's sixteen sample directions; rho = NaN when the cone is not usable.
+// corner[c]: pt_world.xyz - ro.xyz of corner sample c (samples (0,0), (3,0), (0,3), (3,3)), as gen_ray computes it before its
+// normalisation; the caller's sky / floor tests reuse them.  m_proj / m_view: the matrices (in vector registers), off: the
+// table of the sixteen sample offsets.
+RM_DEV bool pixel_misses_scene_v5(const CullTables& T, const float2* aux, const float* m_proj, const float* m_view, const float* off,
+                                  const V4& ro, float sx, float sy, float (&cone_out)[4], float (&corner)[4][3]) {
     float cx = 0.0f, cy = 0.0f, cz = 0.0f, ex[4], ey[4], ez[4];
 #pragma unroll
     for (uint32_t c = 0; c < 4u; c++) {
-        gen_ray_unnormalized(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex[c], ey[c], ez[c]);  // unit_dir normalises
+        const uint32_t s = ((c & 1u) * 3u) * 4u + (c >> 1) * 3u;  // sample (i, j) = table entry 4 i + j
+        gen_ray_unnormalized_at(m_proj, m_view, ro, sx, sy, off[2u * s], off[2u * s + 1u], ex[c], ey[c], ez[c]);  // unit_dir normalises
+        corner[c][0] = ex[c]; corner[c][1] = ey[c]; corner[c][2] = ez[c];
         unit_dir(ex[c], ey[c], ez[c]);
         cx += ex[c]; cy += ey[c]; cz += ez[c];
     }
@@ -1038,6 +1046,9 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     const V4 ro = matvec(u.inv_view, 0.0f, 0.0f, 0.0f, 1.0f);
     const bool tables = (L.flags & 1u) != 0u;
     __shared__ float s_off[32];  // screen offsets of the 16 AA samples: the same for every pixel, computed once
+    __shared__ float s_sxy[V5_PRE_TILES][128];          // per wave: pixel centres, sample codes and the list of the pixels that
+    __shared__ uint8_t s_code[V5_PRE_TILES][64 * 16];   // need them, for the sample-parallel finish of a clear tile (below)
+    __shared__ uint8_t s_list[V5_PRE_TILES][64];
     if (tid == 0u) *s_veto = 0u;
     if (tid < 16u) sample_offset(u, tid >> 2, tid & 3u, s_off[2u * tid], s_off[2u * tid + 1u]);
     __syncthreads();
@@ -1064,19 +1075,32 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
         }
     }
     __syncthreads();
-    const uint32_t tile = blockIdx.x * V5_PRE_TILES + wave;
-    if (tile >= n_tiles) return;  // whole wave; no barrier follows
     const uint32_t tiles_x = (L.W + 7u) / 8u;
+  auto do_tile = [&](uint32_t tile) {  // (whole wave; no barrier inside)
     const uint32_t tile_x = tile % tiles_x, tile_y = tile / tiles_x;
     const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
     const uint32_t px = tx < L.W ? tx : L.W - 1u, ry = ty < L.rows ? ty : L.rows - 1u;
     const float sx = screen_x(px, L.W), sy = screen_y(rm_global_row(L, ry), L.H);
+    // the two matrices in vector registers (32 of them): as scalar operands every multiply of the mat-vecs -- the four corner rays
+    // here, the sixteen sample rays of the finishing loop -- would issue at half rate
+    float mp[16], mv[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        mp[k] = u.inv_proj[k]; mv[k] = u.inv_view[k];
+        asm volatile("" : "+v"(mp[k]), "+v"(mv[k]));
+    }
     bool clear;
-    if (L.max_iter == 0u) clear = true;  // no march step is ever taken: every ray is a miss (wgsl:92)
-    else if (!tables) clear = false;
-    else {
+    float corner[4][3];  // pt_world.xyz - ro.xyz of the pixel's four corner samples
+    if (L.max_iter == 0u || !tables) {
+        clear = L.max_iter == 0u;  // no march step is ever taken: every ray is a miss (wgsl:92); without tables nothing is known
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++) {
+            const uint32_t s = ((c & 1u) * 3u) * 4u + (c >> 1) * 3u;
+            gen_ray_unnormalized_at(mp, mv, ro, sx, sy, s_off[2u * s], s_off[2u * s + 1u], corner[c][0], corner[c][1], corner[c][2]);
+        }
+    } else {
         float cone[4];
-        clear = pixel_misses_scene_v5(cullt, t_aux, u, ro, sx, sy, cone);
+        clear = pixel_misses_scene_v5(cullt, t_aux, mp, mv, s_off, ro, sx, sy, cone, corner);
         // a program that blends: the pixels the inflated bounds could not clear get the program run on lower bounds of its
         // leaves over the pixel's cone ("Miss test on lower bounds"; the march kernel repeats it per ray for what is left)
         const float bound_scale = (L.scene_scale + L.smooth_slack) + ((__builtin_fabsf(ro.x) + __builtin_fabsf(ro.y)) + __builtin_fabsf(ro.z));
@@ -1094,6 +1118,8 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
     const uint32_t pending = (uint32_t)__popcll(__ballot(!clear));
     if (lane == 0u) cost[(size_t)blockIdx.z * n_tiles + tile] = pending;  // 0 = finished here
     if (pending != 0u) return;
+    bool known = false;   // this pixel's sixteen samples provably share one colour code ...
+    int known_code = -1;  // ... -1 black (sky), 0 / 1 the checker bit
     // Sky: a sample whose ray points away from the floor plane (t <= 0 in wgsl:120-121) is black, and the sum of sixteen
     // zeros is zero.  pt_world.y - ro.y is affine in the sample's screen offset, so its sign over the 4 x 4 grid is decided at
     // the four corner samples up to rounding; with the camera above the plane (-1.5 - ro.y < 0), "all four corners point up by
@@ -1106,10 +1132,8 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
         float lo = __uint_as_float(0x7F800000u);
 #pragma unroll
         for (uint32_t c = 0; c < 4u; c++) {
-            float ex, ey, ez;
-            gen_ray_unnormalized(u, ro, sx, sy, (c & 1u) * 3u, (c >> 1) * 3u, ex, ey, ez);
-            lo = ey < lo ? ey : lo;
-            if (!(ey == ey)) lo = ey;  // a NaN sticks and makes the test below false
+            lo = corner[c][1] < lo ? corner[c][1] : lo;
+            if (!(corner[c][1] == corner[c][1])) lo = corner[c][1];  // a NaN sticks and makes the test below false
         }
         const float bx = __builtin_fabsf(sx) + __builtin_fabsf(s_off[0]), by = __builtin_fabsf(sy) + __builtin_fabsf(s_off[1]);  // sample (0, 0) has the largest offsets
         float mag = __builtin_fabsf(ro.y);
@@ -1122,18 +1146,61 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
             if (tx < L.W && ty < L.rows) store_pixel(L, blockIdx.z, (size_t)ty * L.W + tx, 0.0f, 0.0f, 0.0f);  // 0 / 16 = 0 (wgsl:73-75)
             return;
         }
-    }
-    // This loop is most of the pre-pass (60 % of the metric frame's pixels x 16 samples).  Everything that does not depend on
-    // the pixel is taken out of it: the sample offsets (two divisions each) come from the table above, the matrices sit in
-    // vector registers (32 of them; as scalar operands every multiply of the two mat-vecs would issue at half rate), and the
-    // gamma-corrected colour of a sample is one of three values -- black, or the checker colour for bit 0 / 1 (wgsl:127) --
-    // whose square roots are taken once, by the same expressions.
-    float mp[16], mv[16];
+        // Floor, one checker cell per pixel.  With every sample ray pointing down (t > 0) the floor point of a sample is
+        // fx = o.x + C ex / ey, C = -1.5 - o.y (the normalisation cancels), a linear-fractional function of the sample's screen
+        // position: monotone along every segment where ey keeps its sign, so over the pixel's rectangle of samples it stays between
+        // its values at the four corner samples.  If the interval those span -- widened by everything rounding can do to a
+        // sample's own fx: the mat-vec errors E (4e-6 of `mag`, per component) pushed through |C| / |ey| (E_x + |ex| E_y / |ey|),
+        // once for the corners and once for the sample, the approximate reciprocal used here and the five roundings of the
+        // sample's own chain -- rounds to ONE integer after the +0.5 of wgsl:124 (rint is monotone), and the same holds for z,
+        // all sixteen samples carry the same checker bit, and the pixel is the sum of sixteen equal gamma values: a constant
+        // per bit, accumulated below exactly as the loop would.  A tile whose 64 pixels are each sky or such a pixel skips the
+        // loop: what remains for it are the pixels a cell edge crosses, the horizon and the far floor.
+        const float Cf = -1.5f - ro.y;  // as shade_floor computes it
+        float ex[4], eyc[4], ez[4], ey_hi = -__uint_as_float(0x7F800000u), ax_hi = 0.0f, az_hi = 0.0f;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        mp[k] = u.inv_proj[k]; mv[k] = u.inv_view[k];
-        asm volatile("" : "+v"(mp[k]), "+v"(mv[k]));
+        for (uint32_t c = 0; c < 4u; c++) {
+            ex[c] = corner[c][0]; eyc[c] = corner[c][1]; ez[c] = corner[c][2];
+            ey_hi = eyc[c] > ey_hi ? eyc[c] : ey_hi;
+            if (!(eyc[c] == eyc[c])) ey_hi = eyc[c];
+            ax_hi = fmax_(ax_hi, __builtin_fabsf(ex[c]));
+            az_hi = fmax_(az_hi, __builtin_fabsf(ez[c]));
+        }
+        float mag_x = __builtin_fabsf(ro.x), mag_z = __builtin_fabsf(ro.z);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float pvk = ((__builtin_fabsf(u.inv_proj[k]) * bx + __builtin_fabsf(u.inv_proj[k + 4]) * by) + __builtin_fabsf(u.inv_proj[k + 8])) +
+                              __builtin_fabsf(u.inv_proj[k + 12]);
+            mag_x += __builtin_fabsf(u.inv_view[0 + 4 * k]) * pvk;
+            mag_z += __builtin_fabsf(u.inv_view[2 + 4 * k]) * pvk;
+        }
+        const float Ey = 4.0e-6f * mag, Ex = 4.0e-6f * mag_x, Ez = 4.0e-6f * mag_z;
+        const float my = -ey_hi - 2.0f * Ey;  // every sample's |ey| is at least this
+        bool uniform = Cf < -1.0e-20f && my > 0.0f && ey_hi < -4.0f * Ey;
+        const float inv_my = __builtin_amdgcn_rcpf(my) * 1.00001f, absC = -Cf;
+        float gx_lo = __uint_as_float(0x7F800000u), gx_hi = -gx_lo, gz_lo = gx_lo, gz_hi = -gx_lo;
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++) {
+            const float r = __builtin_amdgcn_rcpf(eyc[c]);
+            const float gx = ex[c] * r, gz = ez[c] * r;
+            gx_lo = fmin_(gx_lo, gx); gx_hi = fmax_(gx_hi, gx);
+            gz_lo = fmin_(gz_lo, gz); gz_hi = fmax_(gz_hi, gz);
+            uniform = uniform && gx == gx && gz == gz;  // (v_min / v_max drop a NaN)
+        }
+        // C < 0: the interval of fx - o.x is [C gx_hi, C gx_lo]
+        const float dx_lo = Cf * gx_hi, dx_hi = Cf * gx_lo, dz_lo = Cf * gz_hi, dz_hi = Cf * gz_lo;
+        const float dev_x = fmax_(__builtin_fabsf(dx_lo), __builtin_fabsf(dx_hi)), dev_z = fmax_(__builtin_fabsf(dz_lo), __builtin_fabsf(dz_hi));
+        const float del_x = 4.0f * (absC * inv_my) * (Ex + ((ax_hi + Ex) * inv_my) * Ey) + 2.0e-5f * ((1.0f + __builtin_fabsf(ro.x)) + dev_x);
+        const float del_z = 4.0f * (absC * inv_my) * (Ez + ((az_hi + Ez) * inv_my) * Ey) + 2.0e-5f * ((1.0f + __builtin_fabsf(ro.z)) + dev_z);
+        const float nx = __builtin_rintf(((ro.x + dx_lo) - del_x) + 0.5f), nz = __builtin_rintf(((ro.z + dz_lo) - del_z) + 0.5f);
+        uniform = uniform && nx == __builtin_rintf(((ro.x + dx_hi) + del_x) + 0.5f) && nz == __builtin_rintf(((ro.z + dz_hi) + del_z) + 0.5f);
+        known = sky || uniform;
+        known_code = sky ? -1 : ((__float2int_rz(nx) ^ __float2int_rz(nz)) & 1);  // as shade_floor: saturating, wgsl:124-126
     }
+    // The sample loop.  Everything that does not depend on the pixel is taken out of it: the sample offsets (two divisions each)
+    // come from the table, the matrices sit in vector registers, and the gamma-corrected colour of a sample is one of three
+    // values -- black, or the checker colour for bit 0 / 1 (wgsl:127) -- whose square roots are taken once, by the same
+    // expressions.
     float gamma_rg[2], gamma_b[2];
 #pragma unroll
     for (int c = 0; c < 2; c++) {
@@ -1141,19 +1208,61 @@ __global__ __launch_bounds__(64 * V5_PRE_TILES) void rm_tile_pre_v5(RmLaunch L, 
         gamma_rg[c] = __builtin_sqrtf(0.1f + g);
         gamma_b[c] = __builtin_sqrtf(0.2f + g);
     }
+    auto gamma_of = [&](int c, float& rg, float& b) {
+        rg = c < 0 ? 0.0f : (c ? gamma_rg[1] : gamma_rg[0]);  // sqrt(0) = 0 (wgsl:130)
+        b = c < 0 ? 0.0f : (c ? gamma_b[1] : gamma_b[0]);
+    };
     float tr = 0.0f, tg = 0.0f, tb = 0.0f;
-    for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
-        float dx, dy, dz;
-        gen_ray_at(mp, mv, ro, sx, sy, s_off[2u * s], s_off[2u * s + 1u], dx, dy, dz);
-        const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
-        const float rg = c < 0 ? 0.0f : (c ? gamma_rg[1] : gamma_rg[0]);  // sqrt(0) = 0 (wgsl:130)
-        const float b = c < 0 ? 0.0f : (c ? gamma_b[1] : gamma_b[0]);
-        tr += rg;
-        tg += rg;
-        tb += b;
+    const unsigned long long need = __ballot(!known);  // pixels whose samples have to be looked at one by one
+    const uint32_t n_need = (uint32_t)__popcll(need);
+    const uint32_t need_max = (L.flags >> 8) & 0x7Fu ? ((L.flags >> 8) & 0x7Fu) - 1u : 24u;  // (diagnostics: RM_PRE_NEED_MAX)
+    if (n_need <= need_max) {
+        // Few such pixels (a checker edge crossing the tile): their samples -- 16 n_need of them -- are spread over the 64
+        // lanes, 64 per pass instead of one sample of all 64 pixels per pass; each sample's colour code goes to LDS and the
+        // pixel's lane then adds its sixteen gamma values in the reference order.  Same functions, same sums.
+        float* w_sxy = s_sxy[wave];
+        uint8_t* w_code = s_code[wave];
+        uint8_t* w_list = s_list[wave];
+        w_sxy[lane] = sx; w_sxy[64u + lane] = sy;
+        if (!known) w_list[lane_rank(need)] = (uint8_t)lane;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t base = 0u; base < 16u * n_need; base += 64u) {
+            const uint32_t item = base + lane, q = item >> 4, s = item & 15u;
+            const uint32_t pl = w_list[q < n_need ? q : 0u];
+            float dx, dy, dz;
+            gen_ray_at(mp, mv, ro, w_sxy[pl], w_sxy[64u + pl], s_off[2u * s], s_off[2u * s + 1u], dx, dy, dz);
+            const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
+            if (q < n_need) w_code[pl * 16u + s] = (uint8_t)(c + 1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
+            const int c = known ? known_code : (int)w_code[lane * 16u + s] - 1;
+            float rg, b;
+            gamma_of(c, rg, b);
+            tr += rg;
+            tg += rg;
+            tb += b;
+        }
+    } else {
+        for (uint32_t s = 0; s < 16u; s++) {  // reference order: wgsl:44-45, 68-69
+            float dx, dy, dz;
+            gen_ray_at(mp, mv, ro, sx, sy, s_off[2u * s], s_off[2u * s + 1u], dx, dy, dz);
+            const int c = shade_floor(ro.y, ro.x, ro.z, dx, dy, dz);  // wgsl:117-130
+            float rg, b;
+            gamma_of(c, rg, b);
+            tr += rg;
+            tg += rg;
+            tb += b;
+        }
     }
     if (tx < L.W && ty < L.rows) {
         store_pixel(L, blockIdx.z, (size_t)ty * L.W + tx, tr / 16.0f, tg / 16.0f, tb / 16.0f);  // wgsl:73-75
+    }
+  };
+    const uint32_t first_tile = (blockIdx.x * V5_PRE_TILES + wave) * V5_PRE_TILES_PER_WAVE;
+    for (uint32_t t = 0; t < V5_PRE_TILES_PER_WAVE && first_tile + t < n_tiles; t++) {
+        do_tile(first_tile + t);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the wave's LDS scratch is reused by its next tile
     }
 }
 #endif

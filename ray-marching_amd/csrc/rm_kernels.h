@@ -77,6 +77,12 @@ RM_DEV void gen_ray(const rm_uniforms& u, const V4& ro, float sx, float sy, uint
 
 // The same ray up to a positive factor, for the miss tests only (they normalise with unit_dir themselves): pt_world - ro_world
 // without wgsl:62's vec4 normalize -- no sqrt, no three correctly rounded divisions.  NOT a value of the arithmetic contract.
+RM_DEV void gen_ray_unnormalized_at(const float* m_proj, const float* m_view, const V4& ro, float sx, float sy, float ox, float oy,
+                                    float& ex, float& ey, float& ez) {
+    V4 pv = matvec(m_proj, sx + ox, sy + oy, -1.0f, 1.0f);
+    V4 pw = matvec(m_view, pv.x, pv.y, pv.z, pv.w);
+    ex = pw.x - ro.x; ey = pw.y - ro.y; ez = pw.z - ro.z;
+}
 RM_DEV void gen_ray_unnormalized(const rm_uniforms& u, const V4& ro, float sx, float sy, uint32_t i, uint32_t j,
                                  float& ex, float& ey, float& ez) {
     float rx = ((float)i + 0.5f) / 4.0f - 0.5f;
