@@ -8,8 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ray_marching_amd import _ffi, camera, csg, renderer
 
-W, H, K = 1920, 1080, 300
-for n in (1, 2, 3):
+W, H, K = 1920, 1080, 600
+for n in (1, 2, 3, 4, 6, 8):
     ctx, streams, outs = [], [], []
     for i in range(n):
         r = renderer.RayMarchingResources(0)
