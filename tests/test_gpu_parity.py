@@ -962,6 +962,35 @@ def test_subtracted_primitives_leave_the_miss_tests(res, oracle, kernel):
     res.resize_command_buffer(1024)
 
 
+def test_floor_and_sky_tiles_vs_oracle(res, oracle):
+    """Tiles no primitive touches are finished in the pre-pass: sky pixels are zeros, a floor pixel whose sixteen samples
+    provably land in one checker cell is sixteen equal terms, the pixels a cell edge crosses are sampled one by one (few per
+    tile: sample-parallel; many: the plain loop).  Frames that are almost all floor and sky, from cameras that stress the
+    bounds: close to the floor plane, grazing along it (cells shrink to sub-pixel size towards the horizon), straight down,
+    from below the plane (nothing is assumed there), zoomed far in (one cell edge across the frame), off-axis; every pixel
+    against the oracle."""
+    W, H = 320, 200
+    t = scenes._Tab()
+    nodes, root = t.nodes, t.op(scenes.SUBTRACTION, t.sphere((0.0, 0.3, 0.0), 0.35), t.box((0.2, 0.4, 0.0), (0.2, 0.2, 0.2)))
+    cc, w = oracle.serialize(nodes, root)
+    cams = {
+        "still": dict(events=scenes.STILL_CAMERA_EVENTS),
+        "low_over_the_floor": dict(target=(0.0, -1.2, 0.0), events=[(1, 20.0, -4.0), (2, -40.0, 0.0)]),
+        "grazing": dict(target=(0.0, -1.45, 0.0), events=[(1, 140.0, -1.0)]),
+        "straight_down": dict(events=[(1, 0.0, -150.0)]),
+        "from_below": dict(target=(0.0, -3.0, 0.0), events=[(1, 30.0, 60.0)]),
+        "zoomed_in": dict(target=(0.3, -1.5, 0.2), events=[(1, 15.0, -60.0), (2, -97.0, 0.0)]),
+        "panned": dict(events=[(1, 35.0, -25.0), (0, 400.0, -150.0)]),
+        "far": dict(events=[(1, -60.0, -30.0), (2, 600.0, 0.0)]),
+    }
+    for fmt in (_ffi.RM_FORMAT_RGBA32F,):
+        for name, spec in cams.items():
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), **spec)
+            for lim in ((0.01, 100.0, 64), (0.01, 100.0, 0)):          # max_iter = 0: every ray is a miss, every tile is finished there
+                setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=_ffi.RM_KERNEL_DEFAULT)
+                assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=8))
+
+
 def test_draw_is_stream_capturable(oracle):
     """After its first (allocating, compiling) draw of a size, rm_draw with a device destination issues nothing but
     kernel launches on the caller's stream: it can be captured into a HIP graph and replayed."""
