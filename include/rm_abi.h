@@ -110,7 +110,8 @@ enum rm_option {
     RM_OPT_TIMING = 1,     /* 1: bracket every launch of the dominant (march) kernel with HIP events on its stream,
                               without synchronising; read with rm_get_info(RM_INFO_KERNEL_MS) */
     RM_OPT_STRICT_CAP = 2, /* reserved */
-    RM_OPT_REFILL_MIN = 3, /* idle lanes of a wave that trigger a refill from the tile's ray pool, 1..64 (default 1) */
+    RM_OPT_REFILL_MIN = 3, /* idle lanes of a wave that trigger a refill from the tile's ray pool, 1..64; 0 (default): 64 -- a wave
+                              marches its 64 rays in step -- when the kernel prunes far primitives, else 1 */
     RM_OPT_CULL = 4,       /* 1 (default) = shade rays that provably miss the scene without marching (exact) */
     RM_OPT_BALANCE = 5,    /* dispatch order of the tiles that need marching (it never changes a pixel): 0 raster order;
                               1 most pending pixels first; 2 partially covered tiles first; 3 (default) the tiles that

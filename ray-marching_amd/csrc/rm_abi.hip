@@ -75,7 +75,7 @@ struct rm_ctx {
     size_t d_frames_cap = 0;
     // options / info
     int kernel = RM_KERNEL_DEFAULT;
-    uint32_t refill_min_v5 = 1;
+    uint32_t refill_min_v5 = 0;  // 0: by what the kernel does with coherent rays (launch_v5_w)
     bool cull = true;
     int balance = 3;  // RM_OPT_BALANCE: 0 raster order, 1 most pending pixels first, 2 partially covered tiles first,
                       // 3 (default) longest tiles of the previous draw of the same shape first
@@ -417,19 +417,27 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // reference-only programs run the lean interpreter; extension node types select the wider one
     const bool ext = c->decoded.has_extensions;
     c->last_specialized = spec_fn != nullptr;
+    // When a wave takes new rays.  With far-primitive pruning every evaluation tests which primitives are near for ANY lane:
+    // lanes at unrelated march depths (a lane refilled the moment it retires) keep most of them near, while 64 rays started
+    // together stay in step -- far from everything at first, then close to one or two primitives each -- and the union shrinks
+    // with them.  That is worth more than the lanes that idle until the last ray of the batch is done (metric frame 0.505 ->
+    // 0.482 ms, 64-node scene +7 %; profiles/r02_refill_threshold_ab.txt); without pruning nothing is gained and the idle
+    // lanes cost (8-node scene -17 %, the blended scene -2 %), so those kernels keep refilling lane by lane.
+    const bool pruning = spec_fn ? (c->spec && c->spec_pruned) : (L.flags & 8u) != 0u;
+    const uint32_t refill_auto = c->refill_min_v5 != 0u ? c->refill_min_v5 : (pruning ? 64u : 1u);
     if (spec_fn) {
-        uint32_t n_tiles_arg = n_tiles, refill = c->refill_min_v5;
+        uint32_t n_tiles_arg = n_tiles, refill = refill_auto;
         void* args[] = {&L, &work, &n_tiles_arg, &refill};
         hipError_t e = hipModuleLaunchKernel(spec_fn, grid.x, grid.y, grid.z, 64u * WPT, 1, 1, (unsigned)shmem, s, args, nullptr);
         if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "launch of the specialised kernel failed: %s", hipGetErrorString(e));
     } else if (lds && !ext)
-        hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
     else if (lds)
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
     else if (!ext)
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, false>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
     else
-        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, c->refill_min_v5);
+        hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgSmem, false, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
     if (int rc = time_end(c, s)) return rc;
     return finish_launch(c, s);
 }
@@ -991,7 +999,7 @@ RM_EXPORT int rm_set_option(rm_ctx* c, int key, int64_t value) {
         c->waves_per_tile = (int)value;
         return RM_OK;
     case RM_OPT_REFILL_MIN:
-        if (value < 1 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [1,64]", (long long)value);
+        if (value < 0 || value > 64) return fail(c, RM_ERR_ARG, "refill_min %lld not in [0,64]", (long long)value);
         c->refill_min_v5 = (uint32_t)value;
         return RM_OK;
     default: return fail(c, RM_ERR_ARG, "unknown option %d", key);
