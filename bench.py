@@ -104,24 +104,44 @@ def launch_ranks(args, argv):
     return rc
 
 
-def cpu_baseline(args, scene_words, cam_events):
-    """The oracle (a CPU port of the reference shader) timed on the host cores, on a bounded
-    sample: the same scene/camera/limits at 1/div^2 of the pixels (Mpx/s is resolution-normalised)."""
+def oracle_frame(args, scene_words, u_bytes, W, H, cores, want_counters=False):
+    """The oracle's render of one frame from the very 144 uniform bytes the GPU drew with."""
     from oracle import cbind
     cbind.build()
     cc, words = scene_words
-    W, H = args.width // args.cpu_sample_div, args.height // args.cpu_sample_div
+    u = cbind.Uniforms.from_buffer_copy(u_bytes)
+    return cbind.render(u, (0.01, 100.0, args.max_iter), cc, words, W, H, threads=cores, want_counters=want_counters)
+
+
+def cpu_baseline(args, scene_words, u_bytes, W, H):
+    """The oracle (a CPU port of the reference shader) timed on the host cores, on a bounded sample: the same scene / camera /
+    limits at 1/div^2 of the pixels (Mpx/s is resolution-normalised).  The image is kept: it is what `parity` compares the
+    GPU's frames with."""
     cores = host_cores()
-    u, *_ = cbind.orbit_uniforms((float(W), float(H)), events=cam_events)
-    lim = (0.01, 100.0, args.max_iter)
-    cbind.render(u, lim, cc, words, 64, 36, threads=cores)     # warm the threads / caches
+    oracle_frame(args, scene_words, u_bytes, 64, 36, cores)     # warm the threads / caches (any frame will do)
     t0 = time.perf_counter()
-    _, cnt = cbind.render(u, lim, cc, words, W, H, threads=cores, want_counters=True)
+    img, cnt = oracle_frame(args, scene_words, u_bytes, W, H, cores, want_counters=True)
     dt = time.perf_counter() - t0
     return {"value": W * H / dt / 1e6, "unit": "Mpixels/s", "cores": cores, "kind": "port",
             "sample": "%dx%d render (1/%d of the pixels) of the same scene, camera and limits, %.1f s wall"
                       % (W, H, args.cpu_sample_div ** 2, dt),
-            "label": "CPU restatement of the reference shader (oracle/rm_oracle.c), not wgpu"}, cnt, (W, H)
+            "label": "CPU restatement of the reference shader (oracle/rm_oracle.c), not wgpu"}, cnt, img
+
+
+def compare_frames(gpu, ref):
+    """(max |gpu - ref|, pixels with any differing BIT) of two RGBA32F frames.  The contract is bit-exactness; north_star's
+    tolerance is 1e-4 per channel."""
+    import numpy as np
+    a, b = np.ascontiguousarray(gpu, dtype=np.float32), np.ascontiguousarray(ref, dtype=np.float32)
+    if a.shape != b.shape:
+        return float("inf"), int(max(a.size, b.size) // 4)
+    differ = (a.view(np.uint32) != b.view(np.uint32)).any(axis=-1)
+    n = int(differ.sum())
+    if n == 0:
+        return 0.0, 0
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64))
+    d = np.where(np.isnan(d), np.inf, d)        # a NaN on one side only is as wrong as it gets
+    return float(d[differ].max()), n
 
 
 def run_rank(args):
@@ -145,12 +165,17 @@ def run_rank(args):
         raise SystemExit("bench.py: rank %d wants GPU %d, %d visible (one-GPU rehearsal: --all-ranks-on-device0 "
                          "--dist-backend gloo)" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
+    # The process group carries the timing barrier and a MAX reduction, nothing else.  Default group: gloo; RCCL ("nccl") is
+    # probed on top BEFORE any other GPU work and dropped by all ranks together if any of them cannot bring it up
+    # (launch.init_timing_group) -- a timing barrier must not be what loses a multi-GPU run.
+    tgroup, barrier_backend, red_device, group_world, fallback_reason = None, None, "cpu", 1, None
     if world > 1:
-        if args.dist_backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=args.dist_backend)
-    red_device = "cuda" if (world > 1 and args.dist_backend == "nccl") else "cpu"
+        from ray_marching_amd import launch
+        tgroup, barrier_backend, red_device, group_world, fallback_reason = launch.init_timing_group(args.dist_backend, local_rank)
+        if group_world != world:
+            raise SystemExit("bench.py: the process group reports %d ranks, WORLD_SIZE is %d" % (group_world, world))
+        if fallback_reason and rank == 0:
+            sys.stderr.write("bench.py: RCCL barrier group unavailable (%s); using gloo\n" % fallback_reason)
 
     W, H, K = args.width, args.height, args.steps
     mode = args.mode
@@ -187,7 +212,6 @@ def run_rank(args):
     streams = [torch.cuda.Stream() for _ in range(F)]   # kernels, events and syncs of frame f all use stream f % F
     torch.cuda.set_stream(streams[0])
 
-    still_events = [(1, 35.0, -25.0)]                      # Orbit([35,-25]): yaw 0.35, pitch -0.25
     still_ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
     still_ctl.update(camera.Orbit([35.0, -25.0]))
     orbit_ctl = camera.OrbitCameraController.new([0.0, 0.0, 0.0], 5.0)
@@ -204,16 +228,20 @@ def run_rank(args):
     full = [torch.empty((H, W, 4), dtype=torch.float32, device="cuda") for _ in range(F)]          # whole frames
     strips = [torch.empty((max(my_rows, 1), W, 4), dtype=torch.float32, device="cuda") for _ in range(F)] if world > 1 else full
 
-    def sync_all():
+    def barrier():
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=tgroup)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(values):
         if world == 1:
             return [float(v) for v in values]
         t = torch.tensor(list(values), dtype=torch.float64, device=red_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=tgroup)
         return [float(v) for v in t]
 
     def prepare(c, u):
@@ -254,8 +282,7 @@ def run_rank(args):
         if finish:
             finish()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        barrier()
         seconds = time.perf_counter() - t0
         if gc_was_on:
             gc.enable()
@@ -265,6 +292,15 @@ def run_rank(args):
             c.set_option(_ffi.RM_OPT_TIMING, 0)
         seconds, per_draw, kms = max_over_ranks([seconds, per_draw, sum(kms) / len(kms)])
         return seconds, per_draw, kms
+
+    def last_uniforms(us, i, n_ctx):
+        """Uniforms of the last draw timed() made into buffer i (timed step k draws into k % n_ctx with us[warmup + k], warm-up
+        step s into s % n_ctx with us[s]; before that every context drew once with us[0])."""
+        ks = [k for k in range(K) if k % n_ctx == i]
+        if ks:
+            return us[args.warmup + ks[-1]]
+        ws = [w for w in range(args.warmup) if w % n_ctx == i]
+        return us[ws[-1]] if ws else us[0]
 
     cam_stride, cam_offset = (world, rank) if not tile else (1, 0)    # frames mode: rank r renders frames r, r + world, ...
     unis = [uniforms(s, args.camera, cam_stride, cam_offset) for s in range(total)]
@@ -282,27 +318,52 @@ def run_rank(args):
     jit_ms = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
     last = (strips if tile else full)[(K - 1) % F]
     checksum = float(last[..., :3].double().sum().item())                     # touches the result: nothing was skipped
+    # every in-flight buffer as the timed loop left it, with the uniforms of the last draw into it: `parity` (below) compares
+    # ALL of them with the oracle's render of the same uniforms
+    snaps = []
+    if world == 1 and not tile and not args.no_cpu_baseline:
+        for i in range(F):
+            snaps.append((bytes(last_uniforms(unis, i, F)), full[i].cpu().numpy()))
     frames_per_step = 1 if tile else world
     value = W * H * K * frames_per_step / elapsed / 1e6
 
     legs = {}
+    exit_code = 0
+    orbit_snap = None
+    useful_occ = None
     if not args.no_legs:
         # strictly serial loop (one frame in flight): what ONE frame costs, and the only honest source of per-launch
         # durations (with several frames in flight an event-bracketed draw also contains time queued behind the others)
         s_el, s_draw, s_k = timed(1, headline_draw, unis)
         legs["one_frame_in_flight"] = {"value": W * H * K * frames_per_step / s_el / 1e6, "unit": "Mpixels/s",
                                        "draw_ms": s_draw, "kernel_ms": s_k}
+        # USEFUL lane occupancy of the march kernel (one untimed draw with per-wave counters, rm_read_wave_stats): lanes that
+        # carry a live ray (or a waiting hit, in a tap phase) over 64 x the map_scene iterations of all waves.  A wave that
+        # marches its 64 rays in step keeps its exec mask full while the lanes whose rays ended early do dead work: the
+        # exec-mask figure of the PMC pass does not see that, this one does.
+        try:
+            import numpy as np
+            res.set_option(_ffi.RM_OPT_WAVE_STATS, 1)
+            prepare(res, unis[-1])
+            headline_draw(0)
+            torch.cuda.synchronize()
+            st = res.wave_stats()
+            res.set_option(_ffi.RM_OPT_WAVE_STATS, 0)
+            iters = int((st[:, 2] & np.uint64(0xFFFFFFFF)).sum())
+            live = int((st[:, 3] & np.uint64(0xFFFFFFFF)).sum())
+            useful_occ = live / (64.0 * iters) if iters else None
+        except Exception as e:      # diagnostics only
+            sys.stderr.write("bench.py: wave statistics unavailable: %s\n" % e)
+            res.set_option(_ffi.RM_OPT_WAVE_STATS, 0)
         # end to end: the image lands in host memory.  N = 1: D2H into one pinned frame; N > 1: the north-star gather --
         # every rank copies its strips to their rows of ONE shared-memory frame (two frame slots, frame k -> slot k % 2,
         # so frame k + 1 renders while frame k is copied), a per-rank completion counter says when a frame is whole.
         if args.camera == "still" or tile:
             D = 2 if F >= 2 else 1
             name = "rm_bench_%s_%d" % (os.environ.get("MASTER_PORT", "0"), os.getppid() if world > 1 else os.getpid())
-            gloo = dist.new_group(backend="gloo") if (world > 1 and args.dist_backend != "gloo") else None
-
-            def host_barrier():
+            def host_barrier():     # the default group is gloo (host side), whatever carries the timing barrier
                 if world > 1:
-                    dist.barrier(group=gloo) if gloo is not None else dist.barrier()
+                    dist.barrier()
 
             shared = shard.SharedImage(name, W, H, slots=D).open(rank, world, host_barrier)
             shared.register()
@@ -369,6 +430,9 @@ def run_rank(args):
             o_el, _, _ = timed(F, draw_full, ounis)
             legs["orbit_camera"] = {"value": W * H * K / o_el / 1e6, "unit": "Mpixels/s",
                                     "what": "same loop, frame f of a 1024-frame orbit (yaw 2 pi f / 1024, pitch -0.25, r 5)"}
+            if not args.no_cpu_baseline:     # one sampled frame of the leg for `parity`: the last one drawn
+                i_last = (K - 1) % F
+                orbit_snap = (bytes(last_uniforms(ounis, i_last, F)), full[i_last].cpu().numpy(), (args.warmup + K - 1) % 1024)
         if world == 1 and specialized:
             # A/B: the interpreter kernel, i.e. the design north_star spells out (node array staged in LDS and INTERPRETED)
             res.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
@@ -412,7 +476,9 @@ def run_rank(args):
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
                        "step": "prepare (uniform write + command-buffer rewrite, renderer.rs:213-239) + draw, image resident in HBM",
                        "camera": args.camera, "kernel": args.kernel, "specialized_kernel": specialized,
-                       "jit_compile_ms": jit_ms, "frames_in_flight": F, "sharding": sharding},
+                       "jit_compile_ms": jit_ms, "frames_in_flight": F, "sharding": sharding,
+                       "barrier_backend": barrier_backend, "barrier_group_world_size": group_world if world > 1 else None,
+                       "barrier_fallback_reason": fallback_reason},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": ("rm_render_v5_spec (hipRTC-compiled for this scene's structure)" if specialized else "rm_render_v5")
@@ -436,9 +502,41 @@ def run_rank(args):
                 line["roofline"]["measured_write_GBps"] = None
                 line["roofline"]["measured_write_error"] = str(e)
         line.update(legs)
+        parity_ok = True
         if world == 1 and not args.no_cpu_baseline:
-            base, cnt, (cw, ch) = cpu_baseline(args, (cc, words), still_events)
+            import numpy as np
+            div = max(1, args.cpu_sample_div)
+            cw, ch = W // div, H // div
+            sample_u = bytes(renderer.prepare_uniforms((float(cw), float(ch)), still_ctl.camera()))
+            base, cnt, ref_img = cpu_baseline(args, (cc, words), sample_u, cw, ch)
             line["cpu_baseline"] = base
+            # ---- parity: the frames this run TIMED against the oracle's render of the same uniforms, bit for bit ----
+            cores = base["cores"]
+            refs = {sample_u: ref_img} if div == 1 else {}
+            worst, differing, checked = 0.0, 0, 0
+            if div == 1:
+                for ub, img in snaps:                       # every in-flight buffer of the headline loop
+                    if ub not in refs:
+                        refs[ub] = oracle_frame(args, (cc, words), ub, W, H, cores)
+                    d, n = compare_frames(img, refs[ub])
+                    worst, differing, checked = max(worst, d), differing + n, checked + 1
+                what = "every in-flight buffer of the headline loop (%d x %dx%d) as the timed region left it" % (len(snaps), W, H)
+            else:                                           # bounded sample: the reduced frame the CPU baseline rendered
+                res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
+                res.set_uniforms(_ffi.Uniforms.from_buffer_copy(sample_u))
+                d, n = compare_frames(res.draw(cw, ch), ref_img)
+                worst, differing, checked = d, n, 1
+                what = "one %dx%d frame of the same scene and camera (--cpu-sample-div %d: the timed frames are not compared)" % (cw, ch, div)
+            line["parity"] = {"vs": "oracle", "max_abs_diff": worst, "pixels_differing": differing, "frames_checked": checked,
+                              "what": what, "tolerance": "bit-exact (north_star allows 1e-4 per channel)",
+                              "oracle": "oracle/rm_oracle.c, parity unpinned against a real wgpu render (DESIGN 3)"}
+            parity_ok = differing == 0
+            if orbit_snap is not None and "orbit_camera" in line and div == 1:
+                ub, img, f = orbit_snap
+                d, n = compare_frames(img, oracle_frame(args, (cc, words), ub, W, H, cores))
+                line["orbit_camera"]["parity"] = {"vs": "oracle", "max_abs_diff": d, "pixels_differing": n, "frames_checked": 1,
+                                                  "what": "the last frame the leg drew (frame %d of the orbit), %dx%d" % (f, W, H)}
+                parity_ok = parity_ok and n == 0
             if args.camera == "still":
                 # oracle counters -> algorithmic map_scene evaluations of the full-size frame
                 scale = (W * H) / float(cw * ch)
@@ -446,15 +544,19 @@ def run_rank(args):
                 line["compute"] = {"map_scene_evals_per_frame": evals,
                                    "evals_per_s": evals / (launch_kernel_ms * 1e-3),
                                    "note": "evaluations counted by the oracle on the CPU sample, scaled by pixel count"}
-                line["compute"].update(valu_view(args, res, launch_kernel_ms, evals, words))
+                line["compute"].update(valu_view(args, res, launch_kernel_ms, evals, words, useful_occ))
         print(json.dumps(line), flush=True)
+        if not parity_ok:
+            sys.stderr.write("bench.py: the GPU frames differ from the oracle's: %s\n" % json.dumps(line.get("parity")))
+            exit_code = 1
     for c in ctxs:
         c.close()
     if world > 1:
         dist.destroy_process_group()
+    return exit_code
 
 
-def valu_view(args, res, march_ms, evals, words):
+def valu_view(args, res, march_ms, evals, words, useful_occ=None):
     """The honest bound: FP32 vector issue.  Instruction counts and the clock come from the committed PMC
     pass of this configuration (profiles/pmc_traffic.json), the duration from this run (march kernel, one frame in
     flight).  Floor: a wave64 VALU instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md), transcendental
@@ -499,7 +601,12 @@ def valu_view(args, res, march_ms, evals, words):
             "measured_issue_cycles_per_inst": meas_floor,
             "frac_of_measured_valu_issue": meas_floor / cycles_per_inst if meas_floor else None,
             "lds_pipe_busy": pmc.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (simds / 4.0) / (march_ms * 1e-3 * clock_ghz * 1e9) if pmc.get("SQ_ACTIVE_INST_LDS") else None,
-            "executed_fp32_TFLOPs": flop_insts * 64.0 * pmc["lane_occupancy"] / (march_ms * 1e-3) / 1e12,
+            # lanes that carry a live ray (this run's wave counters), not lanes whose exec bit is set (the PMC figure, kept
+            # beside it): a wave marching 64 rays in step executes the lanes whose rays ended early as dead work
+            "useful_lane_occupancy": useful_occ,
+            "exec_mask_lane_occupancy": pmc["lane_occupancy"],
+            "executed_fp32_TFLOPs": flop_insts * 64.0 * (useful_occ if useful_occ else pmc["lane_occupancy"]) / (march_ms * 1e-3) / 1e12,
+            "exec_mask_fp32_TFLOPs": flop_insts * 64.0 * pmc["lane_occupancy"] / (march_ms * 1e-3) / 1e12,
             "peak_fp32_vector_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
             "valu_note": "instruction counts and clock (GRBM_GUI_ACTIVE / 8 / duration): committed rocprofv3 PMC pass of this configuration (" +
                          pmc.get("source", "profiles/") + "); floor: 2 cycles per wave64 VALU instruction on a SIMD-32 (MI355X_MICROARCH.md), "
@@ -515,8 +622,7 @@ def main(argv=None):
     args = parse(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
-    run_rank(args)
-    return 0
+    return run_rank(args)
 
 
 if __name__ == "__main__":

@@ -112,7 +112,9 @@ pub const RM_PROGRAM_IS_CHAIN: usize = 6;
 pub const RM_PROGRAM_PRUNABLE: usize = 7;
 pub const RM_PROGRAM_BOUND_WALK: usize = 8;
 pub const RM_PROGRAM_HAS_XFORMS: usize = 9;
-pub const RM_PROGRAM_FACTS: usize = 10;
+pub const RM_PROGRAM_LEAVES: usize = 10;
+pub const RM_PROGRAM_AUTO_PRUNED: usize = 11;
+pub const RM_PROGRAM_FACTS: usize = 12;
 
 /// `RM_JIT_PRUNE`: OR into `waves_per_tile` of rm_jit_source / rm_jit_compile.
 pub const RM_JIT_PRUNE: c_int = 0x100;
@@ -239,6 +241,10 @@ impl RayMarchingResources {
     /// Returns the number of rows written.
     pub fn draw_strips(&self, width: u32, height: u32, strip_rows: u32, first: u32, stride: u32,
                        out_rgba: &mut [f32]) -> Result<u32, RmError> {
+        // The library writes every row of this GPU's strips: the slice must hold them, or a safe caller could make it
+        // write past the end.  (Arguments the library rejects -- strip_rows 0, first >= stride -- write nothing.)
+        let need = strip_row_count(height, strip_rows, first, stride) as usize * width as usize * 4;
+        assert!(out_rgba.len() >= need, "draw_strips: out_rgba holds {} floats, this GPU's strips need {}", out_rgba.len(), need);
         let mut rows: u32 = 0;
         self.check(unsafe {
             rm_draw_strips(self.ctx, width, height, strip_rows, first, stride, out_rgba.as_mut_ptr(), 0, std::ptr::null_mut(),
@@ -246,6 +252,23 @@ impl RayMarchingResources {
         })?;
         Ok(rows)
     }
+}
+
+/// Output rows of strips `first`, `first + stride`, ... (`strip_rows` rows each; the frame's last strip may be ragged) of an
+/// image `height` rows high: what `rm_draw_strips` renders for one GPU.  0 for arguments the library rejects.
+pub fn strip_row_count(height: u32, strip_rows: u32, first: u32, stride: u32) -> u32 {
+    if strip_rows == 0 || stride == 0 || first >= stride {
+        return 0;
+    }
+    let n_strips = (height + strip_rows - 1) / strip_rows;
+    let mut rows = 0u32;
+    let mut s = first;
+    while s < n_strips {
+        let r0 = s * strip_rows;
+        rows += (height - r0).min(strip_rows);
+        s += stride;
+    }
+    rows
 }
 
 impl Drop for RayMarchingResources {

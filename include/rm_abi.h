@@ -216,11 +216,13 @@ int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_wo
  * (indices RM_PROGRAM_*): records, cone entries and slab entries of the miss-test tables, leaves left out of those tables
  * because they sit in the right operand of a Subtraction, paired far-test groups, value-stack slots the accumulator machine
  * spills, then four 0/1 facts -- chain program (stack-free interpreter loop), prunable (far-primitive pruning applies),
- * miss test on lower bounds applies, program has space transformations.  Same status codes as rm_validate_program. */
+ * miss test on lower bounds applies, program has space transformations --, the sphere + box leaves the program evaluates
+ * (subtracted ones included), and 0/1: the automatic pruning decision (RM_OPT_PRUNE = 2) gives this program the pruned kernel.
+ * Same status codes as rm_validate_program. */
 enum rm_program_fact {
     RM_PROGRAM_RECORDS = 0, RM_PROGRAM_CONES = 1, RM_PROGRAM_SLABS = 2, RM_PROGRAM_SUBTRACTED_LEAVES = 3, RM_PROGRAM_GROUPS = 4,
     RM_PROGRAM_SPILL_DEPTH = 5, RM_PROGRAM_IS_CHAIN = 6, RM_PROGRAM_PRUNABLE = 7, RM_PROGRAM_BOUND_WALK = 8, RM_PROGRAM_HAS_XFORMS = 9,
-    RM_PROGRAM_FACTS = 10
+    RM_PROGRAM_LEAVES = 10, RM_PROGRAM_AUTO_PRUNED = 11, RM_PROGRAM_FACTS = 12
 };
 int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, uint32_t* out, uint32_t n_out);
 

@@ -28,7 +28,8 @@ constexpr uint64_t kRefCmdBufferBytes = 1024;  // renderer.rs:142-147
 constexpr uint64_t kMaxCmdBufferBytes = 65536;
 constexpr uint32_t kMaxDim = 1u << 16;
 constexpr uint32_t kMaxIter = 1u << 16;
-constexpr uint32_t kPruneLeaves = 12;  // RM_OPT_PRUNE = 2: programs with this many spheres + boxes get the pruned kernel
+constexpr uint32_t kPruneLeaves = 12;  // RM_OPT_PRUNE = 2: programs that EVALUATE this many spheres + boxes (RmDecoded::n_leaves: subtracted
+                                        // ones included, they have no miss-test slot but cost the same) get the pruned kernel
 
 thread_local std::string g_create_error;
 
@@ -259,7 +260,7 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
         const bool prune = c->decoded.prunable &&
-                           (c->prune == 1 || (c->prune == 2 && c->decoded.n_sphere + c->decoded.n_box >= kPruneLeaves));
+                           (c->prune == 1 || (c->prune == 2 && c->decoded.n_leaves >= kPruneLeaves));
         c->spec = rmjit::Cache::get().request(c->decoded.rec, c->decoded.mrec, wpt, prune);
         c->spec_pruned = prune;
         c->spec_gen = c->prog_gen;
@@ -590,10 +591,21 @@ void order_with_previous(rm_ctx* c, hipStream_t s) {
             c->last_stream = s;
             return;
         }
-        if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
-            if (hipStreamWaitEvent(s, c->ev_order, 0) != hipSuccess) (void)hipGetLastError();
-        } else {
-            (void)hipGetLastError();
+        // The PREVIOUS stream may be the one that is capturing (capture begun on A, a draw captured there, and now -- before
+        // the capture ends -- a draw on another stream B): an event recorded on A would become a node of A's graph, and B's
+        // wait on it would pull B into that capture (or fail with a capture-isolation error, invalidating it).  Captured work
+        // has not run and cannot race with this draw: nothing to wait for.
+        hipStreamCaptureStatus prev_capturing = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(c->last_stream, &prev_capturing) != hipSuccess) {
+            (void)hipGetLastError();  // the previous stream no longer exists
+            prev_capturing = hipStreamCaptureStatusActive;
+        }
+        if (prev_capturing == hipStreamCaptureStatusNone) {
+            if (hipEventRecord(c->ev_order, c->last_stream) == hipSuccess) {
+                if (hipStreamWaitEvent(s, c->ev_order, 0) != hipSuccess) (void)hipGetLastError();
+            } else {
+                (void)hipGetLastError();
+            }
         }
     }
     c->last_stream = s;
@@ -778,7 +790,8 @@ RM_EXPORT int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_
     uint32_t subtracted = 0u;
     for (const RmRecord& r : d.rec) subtracted += (r.op & RM_OP_NOCULL) != 0u;
     const uint32_t facts[RM_PROGRAM_FACTS] = {(uint32_t)d.rec.size(), d.n_sphere, d.n_box, subtracted, (uint32_t)d.groups.size(), d.spill_depth,
-                                              d.is_chain ? 1u : 0u, d.prunable ? 1u : 0u, d.bound_walk ? 1u : 0u, d.has_xforms ? 1u : 0u};
+                                              d.is_chain ? 1u : 0u, d.prunable ? 1u : 0u, d.bound_walk ? 1u : 0u, d.has_xforms ? 1u : 0u,
+                                              d.n_leaves, d.prunable && d.n_leaves >= kPruneLeaves ? 1u : 0u};
     for (uint32_t i = 0; out && i < n_out && i < (uint32_t)RM_PROGRAM_FACTS; i++) out[i] = facts[i];
     return RM_OK;
 }

@@ -17,6 +17,8 @@ struct RmDecoded {
     uint32_t spill_depth = 0;  // LDS slots the accumulator machine needs
     uint32_t n_sphere = 0, n_box = 0;  // cone / slab entries of the miss-test tables; RmRecord::p[6] = slot
     uint32_t n_plane = 0;              // unbounded primitives: they veto miss-ray culling
+    uint32_t n_leaves = 0;             // sphere + box leaves the program EVALUATES (subtracted ones included, which have no table
+                                       // slot): what the automatic pruning decision (RM_OPT_PRUNE = 2) counts
     bool has_extensions = false;       // uses node types the reference does not implement
     // How far SmoothUnion operators can pull the tree value below the minimum over its leaves: the miss tests and
     // the pixel-cone pre-pass inflate every bound by it.  Tracked per value-stack entry while decoding (slack[]):
@@ -291,6 +293,7 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             std::memcpy(&r.p[6], &slot, 4);
         }
     }
+    for (const RmRecord& r : d.rec) d.n_leaves += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
     if (d.prunable) {  // group spheres, see RmDecoded::groups
         const RmRecord* first = nullptr;
         for (const RmRecord& r : d.rec) {

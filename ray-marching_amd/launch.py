@@ -78,19 +78,74 @@ def run_ranks(world, argv, timeout=None, env=None, echo_stderr=True):
         for p in procs:
             if p.poll() is None:
                 p.terminate()
-        for p in procs:
+        for p in procs[1:]:
             if p.poll() is None:
                 try:
                     p.wait(timeout=10)
                 except subprocess.TimeoutExpired:
                     p.kill()
+                    p.wait()            # reap it: a killed child stays defunct until someone waits for it
+        # Rank 0 wrote to a pipe: communicate() keeps what it has read across a timeout, so only another communicate() returns
+        # ALL of rank 0's output (stdout.read() would return what arrived after the last timeout -- a failed rank's
+        # diagnostics would be truncated or lost).
         if procs[0].stdout is not None and not out0:
             try:
-                out0 = procs[0].stdout.read() or ""
+                out0 = procs[0].communicate(timeout=10)[0] or ""
+            except subprocess.TimeoutExpired:
+                procs[0].kill()
+                try:
+                    out0 = procs[0].communicate(timeout=10)[0] or ""
+                except (subprocess.TimeoutExpired, OSError, ValueError):
+                    pass
             except (OSError, ValueError):
                 pass
+        if procs[0].poll() is None:
+            procs[0].kill()
+            procs[0].wait()
     return rc, out0
 
 
 def python_argv(script, args):
     return [sys.executable, script] + list(args)
+
+
+def init_timing_group(backend="nccl", local_rank=0, timeout_s=120.0):
+    """The process group that carries bench.py's timing barrier and its MAX reduction (nothing else: tiles and frames are
+    independent, there is no collective on the data path).  Call it before any other GPU work.
+
+    The DEFAULT group is always gloo (TCP between the ranks of one node: it has nothing to do with the GPUs and cannot be
+    lost to them).  With backend == "nccl" (RCCL on ROCm) a second group is created on top and probed with one tiny
+    all-reduce; the ranks then agree over gloo whether EVERY rank got through.  If any did not -- RCCL missing, communicator
+    set-up failing on this node, no GPU -- all ranks keep gloo, in the same process (never a re-exec).
+    Returns (group or None for the default group, backend name actually used, device for the reduction tensors, world size
+    the group reports, reason for a fallback or None)."""
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=max(60.0, timeout_s)))
+    world = dist.get_world_size()
+    if backend != "nccl":
+        return None, "gloo", "cpu", world, None
+    ok, why, group = 1, None, None
+    try:
+        if os.environ.get("RM_BENCH_FORCE_NCCL_FAILURE"):
+            raise RuntimeError("RM_BENCH_FORCE_NCCL_FAILURE is set")
+        if not (dist.is_nccl_available() and torch.cuda.is_available()):
+            raise RuntimeError("RCCL or a GPU is not available in this process")
+        group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=timeout_s))
+        t = torch.ones(1, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, group=group)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError("probe all-reduce returned %r, expected %d" % (t.item(), world))
+    except Exception as e:  # noqa: BLE001 -- whatever went wrong, the barrier must not cost the run
+        ok, why = 0, "%s: %s" % (type(e).__name__, e)
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)    # over gloo: every rank learns whether every rank got RCCL up
+    if int(flag.item()) == 1:
+        return group, "nccl", "cuda", dist.get_world_size(group), None
+    if group is not None and ok:
+        why = "another rank could not bring RCCL up"
+    return None, "gloo", "cpu", world, why or "another rank could not bring RCCL up"

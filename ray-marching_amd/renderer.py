@@ -209,7 +209,7 @@ def validate_program(cmd_count, words):
 
 
 PROGRAM_FACTS = ("records", "cones", "slabs", "subtracted_leaves", "groups", "spill_depth", "is_chain", "prunable", "bound_walk",
-                 "has_xforms")
+                 "has_xforms", "leaves", "auto_pruned")
 
 
 def program_info(cmd_count, words):

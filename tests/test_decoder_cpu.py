@@ -29,7 +29,27 @@ def test_metric_scenes(oracle):
     bal = info(oracle, *scenes.g32_balanced())
     assert bal["is_chain"] == 0 and bal["prunable"] == 1 and bal["records"] == 16 + 7   # 8 fused pairs, 7 operators on sub-trees
     assert info(oracle, *scenes.g1()) == dict(records=1, cones=1, slabs=0, subtracted_leaves=0, groups=0, spill_depth=0, is_chain=1,
-                                               prunable=1, bound_walk=0, has_xforms=0)
+                                               prunable=1, bound_walk=0, has_xforms=0, leaves=1, auto_pruned=0)
+    assert g32["leaves"] == 16 and g32["auto_pruned"] == 1 and g64["leaves"] == 32 and g8["leaves"] == 4 and g8["auto_pruned"] == 0
+
+
+def test_automatic_pruning_counts_evaluated_leaves_not_table_slots(oracle):
+    """RM_OPT_PRUNE = 2 gives a program the pruned kernel from 12 sphere / box leaves on: leaves it EVALUATES.  Subtracted
+    leaves have no slot in the miss-test tables (cones + slabs) but cost a march step the same."""
+    t = scenes._Tab()
+    acc = t.sphere((0.0, 0.0, 0.0), 0.5)
+    for k in range(1, 16):                     # a 16-leaf chain, 7 of them subtractors
+        leaf = t.sphere((0.6 * k, 0.0, 0.0), 0.4) if k % 2 else t.box((0.6 * k, 0.0, 0.0), (0.3, 0.3, 0.3))
+        acc = t.op(S if k % 2 == 0 and k <= 14 else U, acc, leaf)
+    i = info(oracle, t.nodes, acc)
+    assert i["leaves"] == 16 and i["subtracted_leaves"] == 7 and i["cones"] + i["slabs"] == 9
+    assert i["prunable"] == 1 and i["auto_pruned"] == 1
+    t = scenes._Tab()
+    acc = t.sphere((0.0, 0.0, 0.0), 0.5)
+    for k in range(1, 11):                     # 11 leaves: below the cut whatever the tables hold
+        acc = t.op(U, acc, t.sphere((0.6 * k, 0.0, 0.0), 0.4))
+    i = info(oracle, t.nodes, acc)
+    assert i["leaves"] == 11 and i["cones"] == 11 and i["auto_pruned"] == 0
 
 
 def test_right_operands_of_a_subtraction_leave_the_tables(oracle):

@@ -1024,6 +1024,47 @@ def test_draw_is_stream_capturable(oracle):
         r.close()
 
 
+def test_host_draw_while_another_stream_still_captures_this_context(oracle):
+    """Capture begun on stream S, a draw of the context captured there, and BEFORE the capture ends a host-destination draw of
+    the same context (which runs on the context's own stream).  The context orders consecutive draws on different streams with
+    an event -- but an event recorded on the capturing stream would become a node of its graph and the wait would drag the
+    host draw's kernels, copy and synchronisation into the capture (or fail it).  Captured work has not run: the host draw
+    simply runs, the capture stays valid, and both images are the oracle's."""
+    import torch
+    W, H = 96, 64
+    cc, w = oracle.serialize(*scenes.g32())
+    u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=scenes.STILL_CAMERA_EVENTS)
+    lim = (0.01, 100.0, 96)
+    ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+    r = renderer.RayMarchingResources(0)
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_limits(lim)
+        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+        r.set_program(cc, w)
+        out = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda")
+        s = torch.cuda.Stream()
+        r.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)       # warm: scratch buffers, compiled kernel
+        s.synchronize()
+        assert r.draw(W, H).tobytes() == ref.tobytes()                   # warm the host path too (its device scratch)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            g.capture_begin(capture_error_mode="relaxed")
+            r.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)
+            host = r.draw(W, H)                                          # capture still open on s
+            r.draw_device(W, H, out.data_ptr(), stream=s.cuda_stream)   # and back on the capturing stream
+            g.capture_end()
+        assert host.tobytes() == ref.tobytes()
+        for _ in range(2):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert out.cpu().numpy().tobytes() == ref.tobytes()
+        assert r.draw(W, H).tobytes() == ref.tobytes()
+    finally:
+        r.close()
+
+
 def test_8k_config_row_bands_vs_oracle(res, oracle):
     """BASELINE configs[3] at its full size (7680x4320, 64-node graph, 512 steps; 518 400 tiles) on the default path:
     sampled row bands bit-exact against the oracle, alpha plane and finiteness of the whole frame."""

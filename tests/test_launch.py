@@ -53,6 +53,73 @@ def test_a_failing_rank_stops_the_others(tmp_path):
     assert time.monotonic() - t0 < 60
 
 
+def test_output_of_a_failing_rank0_is_kept_and_children_are_reaped(tmp_path):
+    """Rank 0 prints its diagnostics and exits non-zero while another rank still sleeps: everything rank 0 wrote comes back
+    (communicate() keeps what it read across its timeouts; a later stdout.read() would not), and no child is left behind."""
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import os, sys, time
+        if os.environ["RANK"] == "0":
+            print("first line of rank 0", flush=True)
+            time.sleep(1.0)            # several communicate() timeouts pass in the parent
+            print("last words of rank 0", flush=True)
+            sys.exit(3)
+        time.sleep(600)
+    """))
+    rc, out = launch.run_ranks(2, [sys.executable, str(script)], timeout=120, echo_stderr=False)
+    assert rc == 3
+    assert "first line of rank 0" in out and "last words of rank 0" in out
+    # nothing of ours is left defunct or running
+    kids = subprocess.run(["ps", "--ppid", str(os.getpid()), "-o", "pid=,stat=,args="], capture_output=True, text=True).stdout
+    assert "rank.py" not in kids, kids
+
+
+def test_timing_group_falls_back_to_gloo_on_every_rank(tmp_path):
+    """bench.py's barrier group (launch.init_timing_group): asked for RCCL where RCCL cannot come up (no GPU here; on a GPU box
+    the test forces the failure), every rank ends up on the same gloo group, in the same process, and the group works."""
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import torch
+        import torch.distributed as dist
+        from ray_marching_amd import launch
+        rank = int(os.environ["RANK"])
+        if rank == 1:
+            os.environ["RM_BENCH_FORCE_NCCL_FAILURE"] = "1"      # one rank failing is enough: all must agree
+        group, backend, device, world, why = launch.init_timing_group("nccl", 0, timeout_s=60)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        dist.barrier(group=group)
+        if rank == 0:
+            print(json.dumps({"backend": backend, "world": world, "max": float(t[0]), "why": why, "group_is_default": group is None}))
+        dist.destroy_process_group()
+    """ % ROOT))
+    rc, out = launch.run_ranks(2, [sys.executable, str(script)], timeout=240)
+    assert rc == 0, out
+    got = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert got["backend"] == "gloo" and got["world"] == 2 and got["max"] == 2.0 and got["group_is_default"] is True
+    assert got["why"]
+
+
+def test_timing_group_gloo_when_asked(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(textwrap.dedent("""
+        import json, os, sys
+        sys.path.insert(0, %r)
+        import torch.distributed as dist
+        from ray_marching_amd import launch
+        group, backend, device, world, why = launch.init_timing_group("gloo", 0)
+        dist.barrier(group=group)
+        if os.environ["RANK"] == "0":
+            print(json.dumps([backend, device, world, why]))
+        dist.destroy_process_group()
+    """ % ROOT))
+    rc, out = launch.run_ranks(2, [sys.executable, str(script)], timeout=240)
+    assert rc == 0
+    assert json.loads([l for l in out.splitlines() if l.startswith("[")][-1]) == ["gloo", "cpu", 2, None]
+
+
 def test_timeout_is_reported(tmp_path):
     script = tmp_path / "rank.py"
     script.write_text("import time\ntime.sleep(600)\n")
@@ -114,6 +181,7 @@ def test_bench_two_ranks_tile_one_frame_and_gather_it():
     assert line["end_to_end"]["value"] > 0 and line["frames_sharded"]["scaling"] == "weak"
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel_ms"] > 0
     assert line["vs_baseline"] is None and line["unit"] == "Mpixels/s"
+    assert line["config"]["barrier_backend"] == "gloo" and line["config"]["barrier_group_world_size"] == 2
 
 
 @pytest.mark.gpu
@@ -134,3 +202,8 @@ def test_bench_one_gpu_line_has_every_contract_key():
     assert line["cpu_baseline"]["kind"] == "port"
     assert line["one_frame_in_flight"]["kernel_ms"] <= line["one_frame_in_flight"]["draw_ms"]
     assert line["ab_interpreter_kernel"]["same_image"] is True and line["end_to_end"]["gathered_frame_identical_to_one_gpu_render"] is True
+    # the line certifies its own frames against the oracle (with --cpu-sample-div: one reduced frame; the default run compares
+    # every in-flight buffer of the timed loop)
+    assert line["parity"]["vs"] == "oracle" and line["parity"]["pixels_differing"] == 0 and line["parity"]["max_abs_diff"] == 0.0
+    assert line["parity"]["frames_checked"] >= 1
+    assert 0.3 < line["compute"]["useful_lane_occupancy"] <= 1.0

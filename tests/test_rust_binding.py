@@ -126,6 +126,38 @@ def test_attributes_sit_on_items_that_accept_them():
     assert src.count("{") == src.count("}") and src.count("(") == src.count(")")
 
 
+def test_safe_wrappers_check_slice_lengths_before_the_library_writes():
+    """A safe fn that hands `out_rgba.as_mut_ptr()` to the library must first assert that the slice holds what the library
+    writes (an unsound API otherwise).  The crate cannot be compiled here, so this is a text check per wrapper -- and the
+    Rust strip_row_count is re-evaluated in Python against the library's own count."""
+    src = rust_source()
+    for fn in re.finditer(r"pub fn (\w+)\(&self[^{]*out_rgba: &mut \[f32\][^{]*\{(.*?)\n    \}\n", src, re.S):
+        body = fn.group(2)
+        assert "out_rgba.as_mut_ptr()" in body
+        assert re.search(r"assert!\(out_rgba\.len\(\) >= ", body[: body.index("out_rgba.as_mut_ptr()")]), fn.group(1)
+    assert len(re.findall(r"pub fn \w+\(&self[^{]*out_rgba: &mut \[f32\]", src)) >= 2          # draw, draw_strips
+    m = re.search(r"pub fn strip_row_count\(height: u32, strip_rows: u32, first: u32, stride: u32\) -> u32 \{(.*?)\n\}\n", src, re.S)
+    assert m
+    def rust_count(height, strip_rows, first, stride):     # the function above, statement for statement
+        if strip_rows == 0 or stride == 0 or first >= stride:
+            return 0
+        n_strips = (height + strip_rows - 1) // strip_rows
+        rows, s = 0, first
+        while s < n_strips:
+            rows += min(height - s * strip_rows, strip_rows)
+            s += stride
+        return rows
+    for stmt in ("let n_strips = (height + strip_rows - 1) / strip_rows;", "rows += (height - r0).min(strip_rows);", "s += stride;"):
+        assert stmt in m.group(1), stmt
+    from ray_marching_amd import shard
+    for H in (1, 15, 16, 17, 1080, 2160):
+        for sr in (8, 16):
+            for stride in (1, 2, 3, 8):
+                assert sum(rust_count(H, sr, f, stride) for f in range(stride)) == H
+                for f in range(stride):
+                    assert rust_count(H, sr, f, stride) == shard.strip_row_count(H, sr, f, stride)
+
+
 def test_crate_files_exist_and_link_the_library():
     toml = open(os.path.join(CRATE, "Cargo.toml")).read()
     assert 'name = "rm_hip"' in toml and 'build = "build.rs"' in toml and 'links = "rm_hip"' in toml
