@@ -166,7 +166,9 @@ enum rm_info {
     RM_INFO_JIT_STATE = 7,       /* specialisation of the current program: 0 none requested, 1 compiling, 2 ready, 3 failed
                                     (rm_jit_log has the reason) */
     RM_INFO_JIT_COMPILE_MS = 8,  /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
-    RM_INFO_PRUNED = 9,          /* 1 when the kernel requested for the current program is the pruned form (RM_OPT_PRUNE) */
+    RM_INFO_PRUNED = 9,          /* which skipping rule the kernel requested for the current program carries (RM_OPT_PRUNE): 0 none,
+                                  * 1 far-primitive pruning on a threshold (min / max programs), 2 the local rule of programs that
+                                  * blend with SmoothUnion */
     RM_INFO_INTERPRETER_LOOP = 10 /* record loop the interpreter kernels ran the program of the last march launch with: 0 the
                                     general one (value stack, every node type; also reported when a specialised kernel ran), 1 the chain loop ("a op b op c ...": no
                                     stack), 2 the chain loop with far pairs of primitives skipped (exact; the default for chains) */
@@ -217,7 +219,8 @@ int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_wo
  * because they sit in the right operand of a Subtraction, paired far-test groups, value-stack slots the accumulator machine
  * spills, then four 0/1 facts -- chain program (stack-free interpreter loop), prunable (far-primitive pruning applies),
  * miss test on lower bounds applies, program has space transformations --, the sphere + box leaves the program evaluates
- * (subtracted ones included), and 0/1: the automatic pruning decision (RM_OPT_PRUNE = 2) gives this program the pruned kernel.
+ * (subtracted ones included), and what the automatic pruning decision (RM_OPT_PRUNE = 2) gives this program: 0 the plain kernel,
+ * 1 / 2 as RM_INFO_PRUNED.
  * Same status codes as rm_validate_program. */
 enum rm_program_fact {
     RM_PROGRAM_RECORDS = 0, RM_PROGRAM_CONES = 1, RM_PROGRAM_SLABS = 2, RM_PROGRAM_SUBTRACTED_LEAVES = 3, RM_PROGRAM_GROUPS = 4,

@@ -31,6 +31,7 @@ constexpr uint32_t kMaxIter = 1u << 16;
 constexpr uint32_t kPruneLeaves = 12;  // RM_OPT_PRUNE = 2: programs that EVALUATE this many spheres + boxes (RmDecoded::n_leaves: subtracted
                                         // ones included, they have no miss-test slot but cost the same) get the pruned kernel
 
+constexpr uint32_t kBlendPruneLeaves = 8;  // ... and programs that blend, the local skipping rule (rm_groups.h), from this many
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -104,7 +105,7 @@ struct rm_ctx {
     std::shared_ptr<rmjit::Entry> spec;
     uint64_t spec_gen = ~0ull;
     int spec_wpt = 0;
-    bool spec_pruned = false;
+    int spec_pruned = 0;            // rmjit::PRUNE_* of the requested kernel
     bool last_specialized = false;  // the last march launch ran a specialised kernel
     int last_loop = 0;              // RM_INFO_INTERPRETER_LOOP of the last march launch
     // stream-ordered uploads (program records, bounds, batch uniforms): four pinned staging buffers, see upload()
@@ -252,6 +253,16 @@ int ensure_materials(rm_ctx* c, hipStream_t s) {
     return RM_OK;
 }
 
+// Which skipping rule the specialised kernel of a program gets (rmjit::PRUNE_*): RM_OPT_PRUNE 0 none, 1 whichever applies, 2
+// (default) whichever applies if the program evaluates enough leaves for the tests to pay.
+int prune_kind(const RmDecoded& d, int option) {
+    if (option == 0) return rmjit::PRUNE_NONE;
+    static const uint32_t blend_leaves = std::getenv("RM_BLEND_PRUNE_LEAVES") ? (uint32_t)std::atoi(std::getenv("RM_BLEND_PRUNE_LEAVES")) : kBlendPruneLeaves;
+    if (d.prunable && (option == 1 || d.n_leaves >= kPruneLeaves)) return rmjit::PRUNE_LATTICE;
+    if (d.blend_prunable && (option == 1 || d.n_leaves >= blend_leaves)) return rmjit::PRUNE_BLEND;
+    return rmjit::PRUNE_NONE;
+}
+
 // The specialised march kernel for the current program and WPT waves per tile on this device, or
 // nullptr: specialisation off, not possible, still compiling (mode 1) or failed -- the caller then
 // launches the interpreter kernel.  Never an error.
@@ -259,8 +270,7 @@ hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
     if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
         // same structure as before (parameters moved): the key lookup finds the same entry
-        const bool prune = c->decoded.prunable &&
-                           (c->prune == 1 || (c->prune == 2 && c->decoded.n_leaves >= kPruneLeaves));
+        const int prune = prune_kind(c->decoded, c->prune);
         c->spec = rmjit::Cache::get().request(c->decoded.rec, c->decoded.mrec, wpt, prune);
         c->spec_pruned = prune;
         c->spec_gen = c->prog_gen;
@@ -424,7 +434,9 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // with them.  That is worth more than the lanes that idle until the last ray of the batch is done (metric frame 0.505 ->
     // 0.482 ms, 64-node scene +7 %; profiles/r02_refill_threshold_ab.txt); without pruning nothing is gained and the idle
     // lanes cost (8-node scene -17 %, the blended scene -2 %), so those kernels keep refilling lane by lane.
-    const bool pruning = spec_fn ? (c->spec && c->spec_pruned) : (L.flags & 8u) != 0u;
+    static const bool blend_in_step = !(std::getenv("RM_BLEND_IN_STEP") && std::atoi(std::getenv("RM_BLEND_IN_STEP")) == 0);  // A/B
+    const bool pruning = spec_fn ? (c->spec && (c->spec_pruned == rmjit::PRUNE_LATTICE || (c->spec_pruned == rmjit::PRUNE_BLEND && blend_in_step)))
+                                 : (L.flags & 8u) != 0u;
     const uint32_t refill_auto = c->refill_min_v5 != 0u ? c->refill_min_v5 : (pruning ? 64u : 1u);
     if (spec_fn) {
         uint32_t n_tiles_arg = n_tiles, refill = refill_auto;
@@ -791,7 +803,7 @@ RM_EXPORT int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_
     for (const RmRecord& r : d.rec) subtracted += (r.op & RM_OP_NOCULL) != 0u;
     const uint32_t facts[RM_PROGRAM_FACTS] = {(uint32_t)d.rec.size(), d.n_sphere, d.n_box, subtracted, (uint32_t)d.groups.size(), d.spill_depth,
                                               d.is_chain ? 1u : 0u, d.prunable ? 1u : 0u, d.bound_walk ? 1u : 0u, d.has_xforms ? 1u : 0u,
-                                              d.n_leaves, d.prunable && d.n_leaves >= kPruneLeaves ? 1u : 0u};
+                                              d.n_leaves, (uint32_t)prune_kind(d, 2)};
     for (uint32_t i = 0; out && i < n_out && i < (uint32_t)RM_PROGRAM_FACTS; i++) out[i] = facts[i];
     return RM_OK;
 }
@@ -1040,7 +1052,7 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     case RM_INFO_CU_COUNT: *out = c->cu_count; return RM_OK;
     case RM_INFO_SPECIALIZED: *out = c->last_specialized ? 1.0 : 0.0; return RM_OK;
     case RM_INFO_INTERPRETER_LOOP: *out = c->last_specialized ? 0.0 : (double)c->last_loop; return RM_OK;
-    case RM_INFO_PRUNED: *out = c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty && c->spec_pruned ? 1.0 : 0.0; return RM_OK;
+    case RM_INFO_PRUNED: *out = c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty ? (double)c->spec_pruned : 0.0; return RM_OK;
     case RM_INFO_JIT_STATE:
     case RM_INFO_JIT_COMPILE_MS: {
         *out = 0.0;
@@ -1147,7 +1159,8 @@ int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int 
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return rc;
-    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, d.mrec, wpt, prune && d.prunable, src)) return RM_ERR_ARG;
+    const int kind = !prune ? rmjit::PRUNE_NONE : d.prunable ? rmjit::PRUNE_LATTICE : d.blend_prunable ? rmjit::PRUNE_BLEND : rmjit::PRUNE_NONE;
+    if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, d.mrec, wpt, kind, src)) return RM_ERR_ARG;
     return RM_OK;
 }
 void copy_out(const std::string& s, char* buf, size_t cap) {

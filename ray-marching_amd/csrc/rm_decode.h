@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "rm_device.h"
+#include "rm_groups.h"
 
 struct RmDecoded {
     std::vector<RmRecord> rec;
@@ -54,6 +55,12 @@ struct RmDecoded {
     // from that by at most ~4e-7 of |p|_1 + |c_i|_1 + rho_i -- near the group, where the test matters, that is within
     // the 2e-6 (|c|_1 + R) added here plus the factor 1.000005 applied to thr + R' by the test.
     std::vector<RmRecord> groups;
+    // The LOCAL skipping rule of programs that blend (rm_groups.h): prunable is false for them (SmoothUnion is not a lattice
+    // operator), `groups` then holds one record per pair of rm_blend_pairs(), in that order, with
+    //   p[3] = p[4] = (k + R') * 1.000005 rounded up,  k = the larger blend radius of the two operators (0 for a Union)
+    // -- what the test adds to the accumulator: a member's value is >= |p - c| - R', so |p - c| >= acc + k + R' (plus the
+    // float margin the test adds) puts both members at least k above the accumulator.
+    bool blend_prunable = false;
     // Space transformations (extension): deepest nesting, and -- because a transformed primitive's parameters no longer
     // say where it is -- one world-space bounding sphere (x, y, z, radius) per bounded primitive for the miss tests.
     // cull_veto: some transform is not a similarity (non-unit quaternion, scale not positive and finite): no culling.
@@ -256,6 +263,9 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
                 if (ptr + 1 > cap_words) return RM_ERR_TRUNCATED;
                 std::memcpy(&r.p[0], words + ptr, 4);
                 ptr += 1;
+                // the blend radius is one of the magnitudes the float margins of the skipping rules scale with
+                const float up = std::nextafterf((float)(1.0 + std::fabs((double)r.p[0])), INFINITY);
+                if (!(up <= d.scene_scale)) d.scene_scale = up;  // also takes a NaN
             }
             if (op == RM_CMD_INTERSECTION || op == RM_CMD_SMOOTH_UNION) d.has_extensions = true;
             if (op == RM_CMD_SMOOTH_UNION) d.prunable = false;  // not a lattice operator
@@ -294,13 +304,9 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         }
     }
     for (const RmRecord& r : d.rec) d.n_leaves += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
-    if (d.prunable) {  // group spheres, see RmDecoded::groups
-        const RmRecord* first = nullptr;
-        for (const RmRecord& r : d.rec) {
-            const uint32_t kind = RM_OP_KIND(r.op);
-            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) continue;
-            if (!first) { first = &r; continue; }
-            const RmRecord* m[2] = {first, &r};
+    // bounding sphere of two sphere / box leaves as a group record; `extra` is added to the radius the tests read
+    auto pair_record = [](const RmRecord& m0, const RmRecord& m1, double extra) {
+            const RmRecord* m[2] = {&m0, &m1};
             double c[3], R = 0.0;
             for (int k = 0; k < 3; k++) c[k] = 0.5 * ((double)m[0]->p[k] + (double)m[1]->p[k]);
             for (int i = 0; i < 2; i++) {
@@ -318,11 +324,29 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             // the centre is rounded to binary32: its displacement (<= an ulp of |c|) is inside the 2e-6 |c|_1 slack
             g.p[0] = (float)c[0]; g.p[1] = (float)c[1]; g.p[2] = (float)c[2];
             // p[3] = p[4] = R' * 1.000005 rounded up: the one radius the test reads, next to the centre (one 16-byte read)
-            g.p[4] = std::nextafterf((float)((double)std::nextafterf((float)R, INFINITY) * 1.000005), INFINITY);
+            g.p[4] = std::nextafterf((float)(((double)std::nextafterf((float)R, INFINITY) + extra) * 1.000005), INFINITY);
             g.p[3] = g.p[4];
-            d.groups.push_back(g);
+            return g;
+    };
+    if (d.prunable) {  // group spheres, see RmDecoded::groups
+        const RmRecord* first = nullptr;
+        for (const RmRecord& r : d.rec) {
+            const uint32_t kind = RM_OP_KIND(r.op);
+            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) continue;
+            if (!first) { first = &r; continue; }
+            d.groups.push_back(pair_record(*first, r, 0.0));
             first = nullptr;
         }
+    }
+    if (!d.prunable && !d.has_xforms && rm_has_blend(d.rec)) {  // the local rule, see RmDecoded::blend_prunable
+        d.blend_prunable = true;
+        auto k_of = [&](int leaf) {
+            const RmLeafUse u = rm_leaf_use(d.rec, (size_t)leaf);
+            const double k = u.k_rec >= 0 ? (double)d.rec[(size_t)u.k_rec].p[0] : 0.0;
+            return k > 0.0 ? k : 0.0;
+        };
+        for (const std::pair<int, int>& pr : rm_blend_pairs(d.rec))
+            d.groups.push_back(pair_record(d.rec[(size_t)pr.first], d.rec[(size_t)pr.second], std::fmax(k_of(pr.first), k_of(pr.second))));
     }
     if (!d.rec.empty()) {
         const RmRecord& r0 = d.rec[0];

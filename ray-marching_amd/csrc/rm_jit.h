@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "rm_device.h"
+#include "rm_groups.h"
 
 namespace rmjit {
 
@@ -111,6 +112,9 @@ inline std::string structure_key(const std::vector<RmRecord>& rec) {
     for (const RmRecord& r : rec) {
         k.push_back("PSBCLXM?"[RM_OP_KIND(r.op)]);
         k.push_back("pusixy??"[RM_OP_MODE(r.op)]);
+        // a SmoothUnion whose k is NaN or infinite takes its leaf out of the local skipping rule, which changes how leaves pair
+        // up (rm_groups.h): part of the structure
+        if (RM_OP_KIND(r.op) == RM_KIND_POP && RM_OP_MODE(r.op) == RM_MODE_SMOOTH && !(r.p[0] == r.p[0] && std::fabs(r.p[0]) < 1.0e30f)) k.push_back('!');
     }
     return k;
 }
@@ -455,6 +459,351 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
 }
 
 
+// ---- programs that blend: the LOCAL skipping rule (rm_groups.h, rm_kernel_v5.h spec_local_near) -----------------------
+// map_scene_spec for a program with SmoothUnion operators.  Everything is evaluated as generate_map_scene(prune = false)
+// would, except the leaves the local rule applies to (right operand of a Union, or of the SmoothUnion that follows): each
+// such leaf -- or a PAIR of them, blended into the same accumulator one after the other -- sits behind the wave-uniform test
+// "is its lower bound less than k above the accumulator for any live lane"; when it is not, leaf and operator are skipped
+// and the result is the accumulator, the very bits the evaluation would have produced.  Subtracted leaves keep the local
+// test of the lattice form (spec_sub_*_near), which needs no threshold either.  `thr` carries only the float margin m.
+inline bool generate_map_scene_blend(const std::vector<RmRecord>& rec, std::string* out) {
+    const int count_mode = jit_knob("RM_JIT_PRUNE_STATS", 0);  // 1 leaves evaluated, 3 near pairs
+    const char* counted = count_mode == 1 ? "n_eval += 1u; " : "";
+    // members of a near pair / leaves without a partner: 1 every local leaf has a test of its own (default), 0 only partnerless
+    // ones, 2 boxes, 3 spheres
+    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 1);
+    const bool upfront = jit_knob("RM_JIT_BLEND_UPFRONT", 1) != 0;  // the pairs' squared distances at the top (their LDS reads go out together)
+    const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0;
+    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
+    const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
+    std::map<int, int> pair_of_first;
+    for (size_t g = 0; g < pairs.size(); g++) pair_of_first[pairs[g].first] = (int)g;
+    std::string s;
+    char line[768];
+    s += "namespace rmk {\n";
+    s += "template <bool FAST>\n";
+    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
+    s += "    const float m = thr;\n";  // the float margin of the local rule; a blend kernel's body passes no threshold
+    s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
+    auto pair_distance = [&](int g) {
+        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, x0, y0, z0, kr%d);\n", g, g,
+                      (unsigned)(rec.size() + (size_t)g) * 8u, g);
+        s += line;
+    };
+    if (upfront)
+        for (size_t g = 0; g < pairs.size(); g++) pair_distance((int)g);
+    std::vector<int> stack;
+    int nv = 0, leaves = 0;
+    auto barrier = [&]() {
+        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+    };
+    // one local leaf and its operator: v<w> (declared by the caller, = v<a>) becomes op(v<a>, leaf) unless the leaf is skipped
+    auto emit_member = [&](size_t i, const RmLeafUse& use, int a, int w, bool test) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op);
+        const unsigned off = (unsigned)i * 8u, koff = use.k_rec >= 0 ? (unsigned)use.k_rec * 8u : 0u;
+        char kexpr[64], open_apply[96];
+        if (use.k_rec >= 0) {
+            std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", koff);
+            std::snprintf(open_apply, sizeof open_apply, "spec_smooth_union(lp + %u, v%d, ", koff, a);
+        } else {
+            std::snprintf(kexpr, sizeof kexpr, "0.0f");
+            std::snprintf(open_apply, sizeof open_apply, "vmin(v%d, ", a);
+        }
+        const char* close_apply = use.k_rec >= 0 ? ", live)" : ")";
+        if (kind == RM_KIND_SPHERE) {
+            if (test)
+                std::snprintf(line, sizeof line,
+                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_local_near(live, a, ((v%d + m) + %s) + lp[%u])) { v%d = %sspec_sphere_v<FAST>(lp + %u, a, tiny)%s; %s} }\n",
+                              off, a, kexpr, off + 3u, w, open_apply, off, close_apply, counted);
+            else
+                std::snprintf(line, sizeof line, "    { v%d = %sspec_sphere<FAST>(lp + %u, x0, y0, z0, tiny)%s; %s}\n", w, open_apply, off, close_apply, counted);
+        } else {
+            if (test)
+                std::snprintf(line, sizeof line,
+                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_local_box_near(live, b.a, (v%d + m) + %s)) { v%d = %sspec_box_v<FAST>(b, tiny)%s; %s} }\n",
+                              off, a, kexpr, w, open_apply, close_apply, counted);
+            else
+                std::snprintf(line, sizeof line, "    { v%d = %sspec_box<FAST>(lp + %u, x0, y0, z0, tiny)%s; %s}\n", w, open_apply, off, close_apply, counted);
+        }
+        s += line;
+    };
+    auto wants_test = [&](uint32_t kind) {
+        return leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
+    };
+    for (size_t i = 0; i < rec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        const unsigned off = (unsigned)i * 8u;
+        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL) return false;  // the local rule is generated for world-space leaves only
+        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+            const int b = stack.back(); stack.pop_back();
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d, live);\n", w, off, a, b);
+            else if (op) std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, v%d);\n", w, op, a, b);
+            else return false;
+            s += line;
+            stack.push_back(w);
+            continue;
+        }
+        const RmLeafUse use = rm_leaf_use(rec, i);
+        if (use.local) {
+            if (stack.empty()) return false;
+            const int a = stack.back(); stack.pop_back();
+            auto pf = pair_of_first.find((int)i);
+            if (pf != pair_of_first.end()) {
+                const int g = pf->second;
+                const size_t j = (size_t)pairs[(size_t)g].second;
+                const RmLeafUse use2 = rm_leaf_use(rec, j);
+                const int w1 = nv++, w2 = nv++;
+                std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n", w1, a, w2, a);
+                s += line;
+                if (!upfront) pair_distance(g);
+                std::snprintf(line, sizeof line, "    if (spec_local_near(live, pa%d, (v%d + m) + kr%d)) {\n%s", g, a, g, count_mode == 3 ? "    n_eval += 1u;\n" : "");
+                s += line;
+                emit_member(i, use, a, w1, wants_test(kind));
+                std::snprintf(line, sizeof line, "    v%d = v%d;\n", w2, w1);
+                s += line;
+                emit_member(j, use2, w1, w2, wants_test(RM_OP_KIND(rec[j].op)));
+                s += "    }\n";
+                stack.push_back(w2);
+                barrier();
+                barrier();
+                i = (size_t)use2.next - 1u;
+            } else {
+                const int w = nv++;
+                std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
+                s += line;
+                emit_member(i, use, a, w, true);
+                stack.push_back(w);
+                barrier();
+                i = (size_t)use.next - 1u;
+            }
+            continue;
+        }
+        if (mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
+        int a = -1;
+        if (mode != RM_MODE_PUSH) {
+            if (stack.empty()) return false;
+            a = stack.back(); stack.pop_back();
+        }
+        const int w = nv++;
+        if (mode == RM_MODE_SUB && sub_tests && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX)) {  // see generate_map_scene
+            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
+            s += line;
+            if (kind == RM_KIND_SPHERE)
+                std::snprintf(line, sizeof line,
+                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) { v%d = vmax_negb(v%d, spec_sphere_v<FAST>(lp + %u, a, tiny)); %s} }\n",
+                              off, off, a, w, a, off, counted);
+            else
+                std::snprintf(line, sizeof line,
+                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_sub_box_near(live, b.a, v%d)) { v%d = vmax_negb(v%d, spec_box_v<FAST>(b, tiny)); %s} }\n",
+                              off, a, w, a, counted);
+            s += line;
+        } else {
+            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
+                           : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
+            if (!fn) return false;
+            char leaf[128];
+            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0, y0, z0)", fn, off);
+            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0, y0, z0, tiny)", fn, off);
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d = %s; %s\n", w, leaf, counted);
+            else std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, %s); %s\n", w, op, a, leaf, counted);
+            s += line;
+        }
+        stack.push_back(w);
+        barrier();
+    }
+    if (stack.empty()) return false;
+    std::snprintf(line, sizeof line, "    return v%d;\n}\n}  // namespace rmk\n", stack.back());
+    s += line;
+    *out = std::move(s);
+    return true;
+}
+
+// The four taps of a hit for a program that blends (see generate_map_scene_taps): the local rule is tested ONCE per leaf or
+// pair, with the bound taken at the hit position c -- eps sqrt(3) from every tap: the caller's margin `thr` carries it --
+// against each tap's own accumulator; a leaf is skipped only when it is far for all four taps of every live lane.
+inline bool generate_map_scene_taps_blend(const std::vector<RmRecord>& rec, std::string* out) {
+    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 1);
+    const bool fence = jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;
+    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
+    const char* knob = std::getenv("RM_JIT_TAPS4_SMOOTH");
+    if (knob && std::atoi(knob) == 0) return false;
+    const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
+    std::map<int, int> pair_of_first;
+    for (size_t g = 0; g < pairs.size(); g++) pair_of_first[pairs[g].first] = (int)g;
+    std::string s;
+    char line[1024];
+    s += "namespace rmk {\n";
+    s += "template <bool FAST>\n";
+    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]) {\n";
+    s += "    const float m = thr;\n";
+    s += "    const float e = 0.0001f;\n";
+    s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
+    s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
+    s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
+    for (size_t g = 0; g < pairs.size(); g++) {
+        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, cx, cy, cz, kr%d);\n", (int)g, (int)g,
+                      (unsigned)(rec.size() + g) * 8u, (int)g);
+        s += line;
+    }
+    std::vector<int> stack;
+    int nv = 0, leaves = 0;
+    auto barrier = [&]() {
+        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+    };
+    auto apply4 = [&](const RmLeafUse& use, int a, int w, const char* leaf_fmt_fn, unsigned off) {
+        // v<w>_t = op(v<a>_t, leaf(tap t)) for the four taps
+        if (use.k_rec >= 0) {
+            std::snprintf(line, sizeof line,
+                          "      { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3};\n"
+                          "        const float sb[4] = {%s(lp + %u, x0_0, y0_0, z0_0, tiny), %s(lp + %u, x0_1, y0_1, z0_1, tiny), %s(lp + %u, x0_2, y0_2, z0_2, tiny), %s(lp + %u, x0_3, y0_3, z0_3, tiny)};\n"
+                          "        float so[4]; spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
+                          a, a, a, a, leaf_fmt_fn, off, leaf_fmt_fn, off, leaf_fmt_fn, off, leaf_fmt_fn, off, (unsigned)use.k_rec * 8u, w, w, w, w);
+            s += line;
+        } else {
+            for (int t = 0; t < 4; t++) {
+                std::snprintf(line, sizeof line, "      v%d_%d = vmin(v%d_%d, %s(lp + %u, x0_%d, y0_%d, z0_%d, tiny));\n", w, t, a, t, leaf_fmt_fn, off, t, t, t);
+                s += line;
+            }
+        }
+    };
+    auto emit_member = [&](size_t i, const RmLeafUse& use, int a, int w, bool test) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op);
+        const unsigned off = (unsigned)i * 8u;
+        char kexpr[64];
+        if (use.k_rec >= 0) std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", (unsigned)use.k_rec * 8u);
+        else std::snprintf(kexpr, sizeof kexpr, "0.0f");
+        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : "spec_box<FAST>";
+        if (test) {
+            if (kind == RM_KIND_SPHERE)
+                std::snprintf(line, sizeof line,
+                              "    { const float kq = %s + lp[%u]; const float rh[4] = {(v%d_0 + m) + kq, (v%d_1 + m) + kq, (v%d_2 + m) + kq, (v%d_3 + m) + kq};\n"
+                              "      if (spec_local_near4(live, spec_sphere_a(lp + %u, cx, cy, cz), rh, true)) {\n", kexpr, off + 3u, a, a, a, a, off);
+            else
+                std::snprintf(line, sizeof line,
+                              "    { const float kq = %s; const float rh[4] = {(v%d_0 + m) + kq, (v%d_1 + m) + kq, (v%d_2 + m) + kq, (v%d_3 + m) + kq};\n"
+                              "      if (spec_local_near4(live, spec_box_a(lp + %u, cx, cy, cz).a, rh, false)) {\n", kexpr, a, a, a, a, off);
+            s += line;
+            apply4(use, a, w, fn, off);
+            s += "      } }\n";
+        } else {
+            s += "    {\n";
+            apply4(use, a, w, fn, off);
+            s += "    }\n";
+        }
+        if (fence) s += "    guard_fence(tiny);\n";
+    };
+    auto wants_test = [&](uint32_t kind) {
+        return leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
+    };
+    for (size_t i = 0; i < rec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        const unsigned off = (unsigned)i * 8u;
+        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL) return false;
+        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+            const int b = stack.back(); stack.pop_back();
+            const int a = stack.back(); stack.pop_back();
+            const int w = nv++;
+            if (mode == RM_MODE_SMOOTH) {
+                std::snprintf(line, sizeof line,
+                              "    float v%d_0, v%d_1, v%d_2, v%d_3;\n"
+                              "    { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3}, sb[4] = {v%d_0, v%d_1, v%d_2, v%d_3}; float so[4];\n"
+                              "      spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
+                              w, w, w, w, a, a, a, a, b, b, b, b, off, w, w, w, w);
+                s += line;
+            } else {
+                if (!op) return false;
+                for (int t = 0; t < 4; t++) {
+                    std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, v%d_%d);\n", w, t, op, a, t, b, t);
+                    s += line;
+                }
+            }
+            stack.push_back(w);
+            continue;
+        }
+        const RmLeafUse use = rm_leaf_use(rec, i);
+        if (use.local) {
+            if (stack.empty()) return false;
+            const int a = stack.back(); stack.pop_back();
+            auto pf = pair_of_first.find((int)i);
+            if (pf != pair_of_first.end()) {
+                const int g = pf->second;
+                const size_t j = (size_t)pairs[(size_t)g].second;
+                const RmLeafUse use2 = rm_leaf_use(rec, j);
+                const int w1 = nv++, w2 = nv++;
+                for (int t = 0; t < 4; t++) {
+                    std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d, v%d_%d = v%d_%d;\n", w1, t, a, t, w2, t, a, t);
+                    s += line;
+                }
+                std::snprintf(line, sizeof line,
+                              "    { const float rh[4] = {(v%d_0 + m) + kr%d, (v%d_1 + m) + kr%d, (v%d_2 + m) + kr%d, (v%d_3 + m) + kr%d};\n"
+                              "    if (spec_local_near4(live, pa%d, rh, true)) {\n", a, g, a, g, a, g, a, g, g);
+                s += line;
+                emit_member(i, use, a, w1, wants_test(kind));
+                for (int t = 0; t < 4; t++) {
+                    std::snprintf(line, sizeof line, "    v%d_%d = v%d_%d;\n", w2, t, w1, t);
+                    s += line;
+                }
+                emit_member(j, use2, w1, w2, wants_test(RM_OP_KIND(rec[j].op)));
+                s += "    } }\n";
+                stack.push_back(w2);
+                barrier();
+                barrier();
+                i = (size_t)use2.next - 1u;
+            } else {
+                const int w = nv++;
+                for (int t = 0; t < 4; t++) {
+                    std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d;\n", w, t, a, t);
+                    s += line;
+                }
+                emit_member(i, use, a, w, true);
+                stack.push_back(w);
+                barrier();
+                i = (size_t)use.next - 1u;
+            }
+            continue;
+        }
+        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
+                       : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
+        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
+        int a = -1;
+        if (mode != RM_MODE_PUSH) {
+            if (stack.empty()) return false;
+            a = stack.back(); stack.pop_back();
+        }
+        const int w = nv++;
+        for (int t = 0; t < 4; t++) {
+            char leaf[192];
+            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0_%d, y0_%d, z0_%d)", fn, off, t, t, t);
+            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0_%d, y0_%d, z0_%d, tiny)", fn, off, t, t, t);
+            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d_%d = %s;\n", w, t, leaf);
+            else std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, %s);\n", w, t, op, a, t, leaf);
+            s += line;
+        }
+        if (fence && kind != RM_KIND_PLANE) s += "    guard_fence(tiny);\n";
+        stack.push_back(w);
+        barrier();
+    }
+    if (stack.empty()) return false;
+    for (int t = 0; t < 4; t++) {
+        std::snprintf(line, sizeof line, "    f[%d] = v%d_%d;\n", t, stack.back(), t);
+        s += line;
+    }
+    s += "}\n}  // namespace rmk\n";
+    *out = std::move(s);
+    return true;
+}
+
+
 // The material walk of a tagged program (rm_interp.h map_scene_material) as straight-line code: one evaluation of the
 // program WITH its Material tags at the position of a hit, every value a (distance, index) pair of named variables --
 // no stack in LDS, no decode.  Distances go through the operations map_scene_material applies (the interpreter's leaf
@@ -590,15 +939,20 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
     return smooth && depth <= 1;
 }
 
-inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, bool prune, std::string* out,
+// prune: 0 every leaf is evaluated, 1 far-primitive pruning on a threshold (lattice programs: rm_kernel_v5.h "Pruning"), 2 the
+// local skipping rule of programs that blend (rm_groups.h)
+enum : int { PRUNE_NONE = 0, PRUNE_LATTICE = 1, PRUNE_BLEND = 2 };
+inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune_kind, std::string* out,
                             bool* walk_generated = nullptr) {
     const bool materials = !mrec.empty();
+    const bool prune = prune_kind == PRUNE_LATTICE, blend = prune_kind == PRUNE_BLEND;
     std::string body, taps, walk;
-    if (!generate_map_scene(rec, prune, &body)) return false;
+    if (!(blend ? generate_map_scene_blend(rec, &body) : generate_map_scene(rec, prune, &body))) return false;
     const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
     if (walk_generated) *walk_generated = walk_spec;
     const char* taps_knob = std::getenv("RM_JIT_TAPS4");  // A/B: RM_JIT_TAPS4=0 keeps the taps on map_scene_spec
-    const bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0) && generate_map_scene_taps(rec, prune, &taps);
+    const bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0) &&
+                       (blend ? generate_map_scene_taps_blend(rec, &taps) : generate_map_scene_taps(rec, prune, &taps));
     std::string s;
     // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
     s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
@@ -607,6 +961,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
          "#define int32_t rm_rtc_i32\n#define int64_t rm_rtc_i64\n";
     s += "#define RM_JIT_TU 1\n";
     if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
+    if (blend) s += "#define RM_JIT_BLEND_PRUNE 1\n";
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
     if (structure_allows_bound_walk(rec)) s += "#define RM_JIT_BOUND_WALK 1\n";
@@ -789,9 +1144,17 @@ public:
     // The entry for (rec structure, wpt); queues its compilation for the worker thread the first time.
     // materials: the program carries Material tags (the kernel gets the material phase; the structure is that of
     // the untagged program)
-    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, bool prune) {
-        // a tagged program's kernel also depends on where its tags sit (the material walk is generated from mrec)
-        const std::string key = std::to_string(wpt) + (prune ? "p" : "") + ":" + structure_key(rec) + (mrec.empty() ? "" : "|m:" + structure_key(mrec));
+    std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune) {
+        // a tagged program's kernel also depends on where its tags sit (the material walk is generated from mrec), and on the
+        // A/B knobs of the generator as the environment holds them now (so that a process may compare two settings)
+        static const char* const knobs[] = {"RM_JIT_BLEND_LEAF_TESTS", "RM_JIT_BLEND_UPFRONT", "RM_JIT_GUARD_FENCE", "RM_JIT_LEAF_TESTS", "RM_JIT_MATERIAL_WALK",
+                                            "RM_JIT_PRIO_LONG_RAYS", "RM_JIT_PRUNE_STATS", "RM_JIT_SCHED_BARRIER", "RM_JIT_SCHED_BARRIER_TAPS",
+                                            "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU"};
+        std::string knob_key;
+        for (const char* name : knobs)
+            if (const char* v = std::getenv(name)) knob_key += std::string("|") + name + "=" + v;
+        const std::string key = std::to_string(wpt) + (prune == PRUNE_LATTICE ? "p" : prune == PRUNE_BLEND ? "b" : "") + ":" + structure_key(rec) +
+                                (mrec.empty() ? "" : "|m:" + structure_key(mrec)) + knob_key;
         std::unique_lock<std::mutex> lk(m_);
         auto it = entries_.find(key);
         if (it != entries_.end()) return it->second;

@@ -149,6 +149,50 @@ RM_DEV bool spec_sub_sphere_near(unsigned long long live, LdsF r, float a, float
 RM_DEV bool spec_sub_box_near(unsigned long long live, float a, float acc) {
     return ((__builtin_amdgcn_ballot_w64(!(a > 0.0f)) | __builtin_amdgcn_ballot_w64(!(acc >= 0.0f))) & live) != 0ull;
 }
+// ---- The LOCAL skipping rule (programs that blend with SmoothUnion; rm_groups.h) ---------------------------------
+// smin_k(acc, v) and min(acc, v) return acc, bit for bit, when v >= acc + k (k = 0 for a Union): h = 0 and
+// min(acc, v) - 0 = acc (spec_smooth_union / exec_command RM_MODE_SMOOTH).  No bound on the scene value is involved and no
+// Lipschitz argument: the test compares a LOWER BOUND of the leaf value at this very position -- sqrt(a) - R, a the squared
+// distance to a bounding sphere of the leaf or of a pair of leaves -- with the accumulator the leaf is about to be blended
+// into.  rhs = (acc + m) + (k + R): the leaf (pair) is skipped when sqrt(a) > rhs for EVERY live lane, i.e. rhs < 0 or
+// a > rhs^2.  m = 4e-6 (scene_scale + |ro|_1 + |q|_1), the margin of "Pruning" above: it covers the leaf's own evaluation
+// error (<= 4e-7 of that scale), the roundings of a, rhs and rhs^2 (<= 2e-7 of sqrt(a) <= |q|_1 + scene_scale each) and the
+// strictness v > acc that the selection by min needs; scene_scale includes the blend radii (rm_decode.h).
+// NaN: an accumulator that is NaN makes both comparisons false (the leaf is evaluated: smin(NaN, v) = v); a NaN position
+// or leaf can only make the leaf value NaN, which smin and min ignore (fmin drops it, h = max(NaN, 0) / k = 0): skipping
+// is what the evaluation would have returned.
+RM_DEV bool spec_local_near(unsigned long long live, float a, float rhs) {
+    const unsigned long long far = __builtin_amdgcn_ballot_w64(a > rhs * rhs) | __builtin_amdgcn_ballot_w64(rhs < 0.0f);
+    return (~far & live) != 0ull;
+}
+// A box's value is sqrt(a) + (inside term) with a = |max(q, 0)|^2, and the inside term is +0 only when a > 0: its lower
+// bound sqrt(a) holds only then, so there is no "rhs < 0" shortcut -- a > rhs^2 >= 0 proves both.
+RM_DEV bool spec_local_box_near(unsigned long long live, float a, float rhs) {
+    return (~__builtin_amdgcn_ballot_w64(a > rhs * rhs) & live) != 0ull;
+}
+// Squared distance to the bounding sphere of a pair (a bound: fused multiply-adds) and what the test adds to the
+// accumulator: kr = (k + R') * 1.000005 (RmDecoded::blend_prunable)
+RM_DEV float spec_pair_a(LdsF r, float qx, float qy, float qz, float& kr) {
+    const lds_f4 p = lds_load4(r);
+    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+    kr = p.w;
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+}
+// The four taps of a hit (map_scene_taps): the bound is taken at the hit position c, eps sqrt(3) from every tap (the
+// caller's margin carries it), against each tap's own accumulator; skipped only if far for all four.
+RM_DEV bool spec_local_near4(unsigned long long live, float a, const float (&rhs)[4], bool sphere_bound) {
+    unsigned long long far = ~0ull;
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        unsigned long long f = __builtin_amdgcn_ballot_w64(a > rhs[t] * rhs[t]);
+        if (sphere_bound) f |= __builtin_amdgcn_ballot_w64(rhs[t] < 0.0f);
+        far &= f;
+    }
+    return (~far & live) != 0ull;
+}
+// the blend radius as the rule uses it: a SmoothUnion with k <= 0 is a plain min
+RM_DEV float spec_local_k(LdsF r) { return fmax_(r[0], 0.0f); }
+
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
     const lds_f4 c = lds_load4(r);       // cx cy cz rx
@@ -756,7 +800,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             // |F(tap)| <= |sd_hit| + eps sqrt(3) + error: the threshold of a tap ("Pruning"); the far test runs at c,
             // another eps sqrt(3) and one more leaf-evaluation error away from every tap
             const float m = kPruneAbs * (prune_scale + (((__builtin_fabsf(cx) + __builtin_fabsf(cy)) + __builtin_fabsf(cz)) + 1.0e-3f));
+#ifdef RM_JIT_BLEND_PRUNE  // the local rule has no threshold: its margin, plus the distance from c to a tap (twice over, as above)
+            const float thr_c = 3.5e-4f + (m + m);
+#else
             const float thr_c = __uint_as_float(hq_rid[e] & ~1023u) * 1.00001f + 3.5e-4f + (m + m);
+#endif
             float f[4];
             SqrtGuard tiny;
             const unsigned long long live4_m = __builtin_amdgcn_ballot_w64(live4);
@@ -799,6 +847,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             is_live = mode == M_MARCH;
             thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
         }
+#ifdef RM_JIT_BLEND_PRUNE  // the local rule (spec_local_near) takes only the float margin m, at march steps and taps alike
+        thr = kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+#endif
         n_iter++;
         const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
         n_live += (uint32_t)__popcll(live_m);

@@ -89,9 +89,9 @@ def test_random_programs_against_the_oracle(oracle, seed):
             res.set_limits(lim)
             res.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
             res.set_program(cc, w)
+            # prune = 1: whichever skipping rule the program admits -- the threshold rule (lattice programs), the local rule
+            # (programs that blend, without transforms), or none
             for spec, prune in ((0, 0), (2, 0), (2, 1)):
-                if prune and not lattice:
-                    continue
                 res.set_option(_ffi.RM_OPT_SPECIALIZE, spec)
                 res.set_option(_ffi.RM_OPT_PRUNE, prune)
                 for cull in (0, 1):

@@ -205,7 +205,9 @@ def test_pruning_policy_by_primitive_count(oracle):
     try:
         r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
         r.set_limits(LIM)
-        for name, want in (("g8", {2: 0, 1: 1, 0: 0}), ("g32", {2: 1, 1: 1, 0: 0}), ("g64", {2: 1, 1: 1, 0: 0})):
+        # g8x (4 leaves, a blend): the local rule of blending programs (RM_INFO_PRUNED = 2) only when forced; g32s (16): by default
+        for name, want in (("g8", {2: 0, 1: 1, 0: 0}), ("g32", {2: 1, 1: 1, 0: 0}), ("g64", {2: 1, 1: 1, 0: 0}),
+                           ("g32s", {2: 2, 1: 2, 0: 0}), ("ext_mix", {2: 0, 1: 2, 0: 0})):
             cc, w, u = case(oracle, ALL[name](), W, H)
             ref = oracle.render(u, LIM, cc, w, W, H, threads=4)
             r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))

@@ -5,6 +5,8 @@ discontinuous the only robust way to meet it is to execute the same IEEE op sequ
 import ctypes as C
 import hashlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -786,7 +788,7 @@ def test_program_change_with_a_frame_in_flight(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5_lds", "v5_spec"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE], ids=["v5_lds", "v5_spec", "v5_spec_prune"])
 def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
     """The miss tests inflate every bound by how far SmoothUnion can pull the tree below its leaves (rm_decode.h:
     max k for a chain, + k/4 where two blended sub-trees meet).  Worst cases: many leaves at the SAME distance from
@@ -833,7 +835,7 @@ def test_smooth_union_slack_bound_is_safe(res, oracle, kernel):
     res.resize_command_buffer(1024)
 
 
-@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC], ids=["v5", "v5_lds", "v5_spec"])
+@pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS, KERNEL_SPEC, KERNEL_SPEC_PRUNE], ids=["v5", "v5_lds", "v5_spec", "v5_spec_prune"])
 def test_miss_test_on_lower_bounds_is_exact(res, oracle, kernel):
     """Programs that blend (SmoothUnion) get a second, sharper miss test for the rays the inflated bounds cannot clear:
     the program run on lower bounds of its leaves along the ray (rm_kernel_v5.h "Miss test on lower bounds").  Random
@@ -1021,6 +1023,97 @@ def test_draw_is_stream_capturable(oracle):
             torch.cuda.synchronize()
             assert out.cpu().numpy().tobytes() == ref.tobytes()
     finally:
+        r.close()
+
+
+@pytest.mark.parametrize("form", ["generated", "generated_no_leaf_tests"])
+def test_local_skipping_rule_of_blending_programs(oracle, form):
+    """Programs that blend skip a leaf (or a pair) whose lower bound is at least k above the accumulator it would be blended
+    into, for every live lane (rm_groups.h, rm_kernel_v5.h spec_local_near): exact only if "at least k above" is decided on
+    the safe side of every rounding.  Scenes built to sit ON the boundary and around it: concentric spheres whose radii differ
+    by exactly k (the second leaf's value is the accumulator + k up to an ulp, everywhere), staircases of leaves each within k
+    of the previous accumulator (every one matters although all but the last are far above the final value), k = 0 / negative /
+    1e-6 / larger than the scene, partners that coincide or are 40 units apart, everything 1000 units from the origin, Unions,
+    Subtractions and an Intersection mixed into the chain -- and the parameters (k included, through zero) moving under ONE
+    compiled kernel."""
+    import math
+    rng = np.random.default_rng(4242)
+    W, H = 80, 56
+    r = renderer.RayMarchingResources(0)
+
+    def chain(t, leaves, ks, ops=None):
+        acc = leaves[0]
+        for j, leaf in enumerate(leaves[1:]):
+            op = ops[j % len(ops)] if ops else "m"
+            if op == "m":
+                acc = t.smooth_union(acc, leaf, ks[j % len(ks)])
+            else:
+                acc = t.op({"u": scenes.UNION, "s": scenes.SUBTRACTION, "i": scenes.INTERSECTION}[op], acc, leaf)
+        return acc
+
+    def cases(offset, kscale):
+        ox, oy, oz = offset
+        out = {}
+        t = scenes._Tab()      # radii differ by exactly k: v_second = v_first + k up to an ulp, at every position
+        out["concentric_plus_k"] = (t.nodes, chain(t, [t.sphere((ox, oy, oz), 1.0), t.sphere((ox, oy, oz), 0.75), t.sphere((ox + 0.5, oy, oz), 0.5),
+                                                      t.sphere((ox + 0.5, oy, oz), 0.25), t.box((ox, oy + 0.2, oz), (0.3, 0.3, 0.3))], [0.25 * kscale]))
+        t = scenes._Tab()      # a staircase along x: each leaf 0.8 k closer to the viewer's side than the one before
+        k = 0.5 * kscale
+        out["staircase"] = (t.nodes, chain(t, [t.sphere((ox - 1.6 + 0.4 * j, oy, oz + 0.1 * j), 0.3) if j % 2 else t.box((ox - 1.6 + 0.4 * j, oy, oz + 0.1 * j), (0.25, 0.3, 0.2))
+                                                 for j in range(9)], [k]))
+        t = scenes._Tab()      # every kind of k in one chain
+        out["mixed_k"] = (t.nodes, chain(t, [t.sphere((ox + 0.7 * math.cos(j), oy + 0.3 * math.sin(2 * j), oz + 0.7 * math.sin(j)), 0.35) for j in range(10)],
+                                           [0.3 * kscale, 0.0, -0.2, 1.0e-6, 7.0 * kscale, 0.05]))
+        t = scenes._Tab()      # unions, subtractions and an intersection between the blends; boxes and spheres
+        lv = [(t.sphere if j % 3 else t.box)((ox + rng.uniform(-1.5, 1.5), oy + rng.uniform(-0.6, 0.6), oz + rng.uniform(-1.5, 1.5)),
+                                             0.4 if j % 3 else (0.3, 0.25, 0.35)) for j in range(14)]
+        out["mixed_ops"] = (t.nodes, chain(t, lv, [0.3 * kscale, 0.6 * kscale], ops="mmusmmummsmim"))
+        t = scenes._Tab()      # partners of a pair: coincident, and 40 units apart (a huge, never-far bounding sphere)
+        lv = []
+        for j in range(10):
+            c = (ox + rng.uniform(-1.2, 1.2), oy + rng.uniform(-0.5, 0.5), oz + rng.uniform(-1.2, 1.2))
+            if j % 4 == 2:
+                c = tuple(t.nodes[lv[-1]][1][:3])
+            if j % 4 == 0 and j:
+                c = (c[0] + 40.0, c[1], c[2] - 25.0)
+            lv.append(t.sphere(c, float(rng.choice([0.4, 0.0, -0.2], p=[0.8, 0.1, 0.1]))) if j % 2 else t.box(c, (0.3, 0.3, 0.3)))
+        out["partners"] = (t.nodes, chain(t, lv, [0.35 * kscale]))
+        t = scenes._Tab()      # blended sub-trees on both sides of a blend, and a cylinder and a plane (never skipped) in the chain
+        left = chain(t, [t.sphere((ox - 0.8, oy, oz), 0.5), t.box((ox - 0.2, oy, oz), (0.3, 0.3, 0.3)), t.cylinder((ox - 0.5, oy + 0.5, oz), 0.2, 0.4)], [0.3 * kscale])
+        right = chain(t, [t.box((ox + 0.8, oy, oz), (0.3, 0.4, 0.3)), t.sphere((ox + 0.4, oy + 0.3, oz), 0.3), t.plane((0.0, 1.0, 0.0), 1.2 - oy), t.sphere((ox + 1.2, oy, oz + 0.4), 0.3)],
+                      [0.2 * kscale, 0.4 * kscale])
+        out["subtrees"] = (t.nodes, t.smooth_union(left, right, 0.5 * kscale))
+        return out
+
+    try:
+        r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
+        r.set_option(_ffi.RM_OPT_PRUNE, 1)
+        r.resize_command_buffer(4096)
+        if form == "generated_no_leaf_tests":
+            os.environ["RM_JIT_BLEND_LEAF_TESTS"] = "0"      # read when a structure is generated: pairs only, members untested
+        for offset in ((0.0, 0.0, 0.0), (800.0, -300.0, 500.0)):
+            for kscale in (1.0, 0.0, -1.0):                  # the same structures again with every k scaled: same compiled kernels
+                for name, (nodes, root) in cases(offset, kscale).items():
+                    cc, w = oracle.serialize(nodes, root)
+                    info = renderer.program_info(cc, w)
+                    assert info["auto_pruned"] in (0, 2) and info["prunable"] == 0, (name, info)
+                    r.set_program(cc, w)
+                    for events in (scenes.STILL_CAMERA_EVENTS, [(1, 170.0, 60.0), (2, -35.0, 0.0)]):
+                        u, *_ = oracle.orbit_uniforms((float(W), float(H)), target=offset, events=events)
+                        r.set_uniforms(_ffi.Uniforms.from_buffer_copy(bytes(u)))
+                        for lim in ((0.01, 100.0, 96), (0.002, 30.0, 200)):
+                            r.set_limits(lim)
+                            ref = oracle.render(u, lim, cc, w, W, H, threads=4)
+                            for cull in (1, 0):
+                                r.set_option(_ffi.RM_OPT_CULL, cull)
+                                img = r.draw(W, H)
+                                assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 2, (name, r.jit_log())
+                                if img.tobytes() != ref.tobytes():
+                                    bad = np.argwhere((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1))
+                                    raise AssertionError("%s offset %s kscale %g events %s limits %s cull %d: %d pixels differ (first %s)"
+                                                         % (name, offset, kscale, events, lim, cull, len(bad), bad[:3].tolist()))
+    finally:
+        os.environ.pop("RM_JIT_BLEND_LEAF_TESTS", None)
         r.close()
 
 
