@@ -469,9 +469,10 @@ inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune
 inline bool generate_map_scene_blend(const std::vector<RmRecord>& rec, std::string* out) {
     const int count_mode = jit_knob("RM_JIT_PRUNE_STATS", 0);  // 1 leaves evaluated, 3 near pairs
     const char* counted = count_mode == 1 ? "n_eval += 1u; " : "";
-    // members of a near pair / leaves without a partner: 1 every local leaf has a test of its own (default), 0 only partnerless
-    // ones, 2 boxes, 3 spheres
-    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 1);
+    // members of a near pair: 0 untested (default; measured, config 3 at 4K: 4.86 ms against 5.01 with a test each: a box's test
+    // needs 14 of the box's 26 vector instructions first), 1 a test each, 2 boxes only, 3 spheres only; leaves without a partner
+    // always have one
+    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);
     const bool upfront = jit_knob("RM_JIT_BLEND_UPFRONT", 1) != 0;  // the pairs' squared distances at the top (their LDS reads go out together)
     const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0;
     const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
@@ -630,7 +631,7 @@ inline bool generate_map_scene_blend(const std::vector<RmRecord>& rec, std::stri
 // pair, with the bound taken at the hit position c -- eps sqrt(3) from every tap: the caller's margin `thr` carries it --
 // against each tap's own accumulator; a leaf is skipped only when it is far for all four taps of every live lane.
 inline bool generate_map_scene_taps_blend(const std::vector<RmRecord>& rec, std::string* out) {
-    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 1);
+    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);
     const bool fence = jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;
     const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
     const char* knob = std::getenv("RM_JIT_TAPS4_SMOOTH");
@@ -804,6 +805,308 @@ inline bool generate_map_scene_taps_blend(const std::vector<RmRecord>& rec, std:
 }
 
 
+// ---- programs that blend, skip sets carried along the ray (rm_kernel_v5.h "Skip sets carried ALONG a ray") ---------------
+// The top level of the program as a chain of UNITS, each starting and ending with one value (the accumulator) on the stack:
+enum : int { BU_START = 0,    // record 0: the leaf that starts the chain
+             BU_SINGLE = 1,   // a local leaf (rm_groups.h) and its Union / SmoothUnion
+             BU_PAIR = 2,     // two of them, tested together
+             BU_SUB = 3,      // a sphere / box fused with a Subtraction: the local test of the lattice form
+             BU_GENERIC = 4 };// anything else that takes the accumulator to its next value: a fused Intersection / cylinder / plane,
+                              // or a sub-tree (pushed, built, popped into the chain by its operator)
+struct BlendUnit { int kind, first, last, second; };  // records [first, last]; second: the pair's second leaf record
+inline bool blend_units(const std::vector<RmRecord>& rec, std::vector<BlendUnit>* out) {
+    if (rec.empty() || RM_OP_MODE(rec[0].op) != RM_MODE_PUSH || (rec[0].op & RM_OP_SPILL)) return false;
+    const uint32_t k0 = RM_OP_KIND(rec[0].op);
+    if (k0 != RM_KIND_SPHERE && k0 != RM_KIND_BOX && k0 != RM_KIND_CYLINDER) return false;
+    std::vector<BlendUnit> u;
+    u.push_back({BU_START, 0, 0, -1});
+    std::map<int, int> second_of;
+    for (const std::pair<int, int>& pr : rm_blend_pairs(rec)) second_of[pr.first] = pr.second;
+    for (size_t i = 1; i < rec.size();) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL || kind == RM_KIND_PLANE || kind == RM_KIND_POP) return false;  // (a POP at depth 1 cannot be)
+        const RmLeafUse use = rm_leaf_use(rec, i);
+        if (use.local) {
+            auto it = second_of.find((int)i);
+            if (it != second_of.end()) {
+                const RmLeafUse use2 = rm_leaf_use(rec, (size_t)it->second);
+                u.push_back({BU_PAIR, (int)i, use2.next - 1, it->second});
+                i = (size_t)use2.next;
+            } else {
+                u.push_back({BU_SINGLE, (int)i, use.next - 1, -1});
+                i = (size_t)use.next;
+            }
+            continue;
+        }
+        if (mode != RM_MODE_PUSH) {  // a leaf fused with its operator
+            u.push_back({mode == RM_MODE_SUB && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX) ? BU_SUB : BU_GENERIC, (int)i, (int)i, -1});
+            i++;
+            continue;
+        }
+        // a pushed leaf that is not a local one: the start of a sub-tree; the unit ends with the operator that pops the chain's
+        // accumulator back (stack depth, counted from the accumulator = 1, returns to 1)
+        int depth = 1;
+        size_t j = i;
+        for (; j < rec.size(); j++) {
+            const uint32_t kj = RM_OP_KIND(rec[j].op), mj = RM_OP_MODE(rec[j].op);
+            if (kj == RM_KIND_XFORM || kj == RM_KIND_MATERIAL || kj == RM_KIND_PLANE) return false;
+            if (kj == RM_KIND_POP) depth--;
+            else if (mj == RM_MODE_PUSH) depth++;
+            if (depth == 1) break;
+        }
+        if (j == rec.size()) return false;  // the program ends with more than one value: not a chain
+        u.push_back({BU_GENERIC, (int)i, (int)j, -1});
+        i = j + 1;
+    }
+    // worth it from a handful of units on; one bit per unit
+    const int min_units = jit_knob("RM_JIT_CACHED_MIN_UNITS", 4);
+    if ((int)u.size() < min_units || u.size() > 64) return false;
+    *out = std::move(u);
+    return true;
+}
+
+// Plain code for records [first, last] of `rec` on a stack of named values (as generate_map_scene without pruning); used for
+// the generic units.  `pfx` prefixes the value names so that two units never collide.
+inline bool emit_plain_records(const std::vector<RmRecord>& rec, int first, int last, std::vector<std::string>& stack, const char* pfx,
+                               const char* counted, std::string& s) {
+    char line[768];
+    int nv = 0;
+    for (int i = first; i <= last; i++) {
+        const uint32_t kind = RM_OP_KIND(rec[(size_t)i].op), mode = RM_OP_MODE(rec[(size_t)i].op);
+        const unsigned off = (unsigned)i * 8u;
+        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
+        char w[48];
+        std::snprintf(w, sizeof w, "%s%d", pfx, nv++);
+        if (kind == RM_KIND_POP) {
+            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+            const std::string b = stack.back(); stack.pop_back();
+            const std::string a = stack.back(); stack.pop_back();
+            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float %s = spec_smooth_union(lp + %u, %s, %s, live);\n", w, off, a.c_str(), b.c_str());
+            else if (op) std::snprintf(line, sizeof line, "    const float %s = %s(%s, %s);\n", w, op, a.c_str(), b.c_str());
+            else return false;
+            s += line;
+            stack.push_back(w);
+            continue;
+        }
+        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>" : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : nullptr;
+        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
+        if (mode == RM_MODE_PUSH) {
+            std::snprintf(line, sizeof line, "    const float %s = %s(lp + %u, x0, y0, z0, tiny); %s\n", w, fn, off, counted);
+        } else {
+            if (stack.empty()) return false;
+            const std::string a = stack.back(); stack.pop_back();
+            std::snprintf(line, sizeof line, "    const float %s = %s(%s, %s(lp + %u, x0, y0, z0, tiny)); %s\n", w, op, a.c_str(), fn, off, counted);
+        }
+        s += line;
+        stack.push_back(w);
+    }
+    return true;
+}
+
+inline bool generate_blend_cached(const std::vector<RmRecord>& rec, std::string* out) {
+    std::vector<BlendUnit> units;
+    if (!blend_units(rec, &units)) return false;
+    const int count_mode = jit_knob("RM_JIT_PRUNE_STATS", 0);  // 1 leaves evaluated
+    const char* counted = count_mode == 1 ? "n_eval += 1u; " : "";
+    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);  // members of a near pair in a REFRESH: 0 untested (default), 1 tested
+    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
+    std::map<int, int> pair_index;  // first leaf record -> index of the pair's group record
+    {
+        const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
+        for (size_t g = 0; g < pairs.size(); g++) pair_index[pairs[g].first] = (int)g;
+    }
+    char line[1024];
+    std::string r, c;  // refresh, cached
+    r += "namespace rmk {\ntemplate <bool FAST>\n"
+         "RM_DEV float map_scene_refresh(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval, SpecCache& cache) {\n"
+         "    const float m = thr;\n    const float x0 = qx, y0 = qy, z0 = qz;\n    float rbud = __uint_as_float(0x7F800000u);\n";
+    c += "namespace rmk {\ntemplate <bool FAST>\n"
+         "RM_DEV float map_scene_cached(LdsF lp, float qx, float qy, float qz, unsigned long long skip, uint32_t jstar, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n"
+         "    const float x0 = qx, y0 = qy, z0 = qz;\n";
+    for (auto& kv : pair_index) {
+        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, x0, y0, z0, kr%d);\n", kv.second, kv.second,
+                      (unsigned)(rec.size() + (size_t)kv.second) * 8u, kv.second);
+        r += line;
+    }
+    int leaves = 0;
+    auto barrier = [&](std::string& s) {
+        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+    };
+    // a local member (leaf record i) in the refresh: vW (declared by the caller, = vA) becomes op(vA, leaf) unless its own test
+    // skips it; an evaluated member is a restart candidate
+    auto refresh_member = [&](size_t i, int a, int w, bool test, unsigned long long bit_if_single) {
+        const RmLeafUse use = rm_leaf_use(rec, i);
+        const uint32_t kind = RM_OP_KIND(rec[i].op);
+        const unsigned off = (unsigned)i * 8u, koff = use.k_rec >= 0 ? (unsigned)use.k_rec * 8u : 0u;
+        char kexpr[64], apply_open[96];
+        if (use.k_rec >= 0) {
+            std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", koff);
+            std::snprintf(apply_open, sizeof apply_open, "spec_smooth_union(lp + %u, v%d, ", koff, a);
+        } else {
+            std::snprintf(kexpr, sizeof kexpr, "0.0f");
+            std::snprintf(apply_open, sizeof apply_open, "vmin(v%d, ", a);
+        }
+        const char* apply_close = use.k_rec >= 0 ? ", live)" : ")";
+        std::snprintf(line, sizeof line, "    { const float kk = %s;\n", kexpr);
+        r += line;
+        if (kind == RM_KIND_SPHERE) {
+            if (test) {
+                std::snprintf(line, sizeof line,
+                              "      const float a = spec_sphere_a(lp + %u, x0, y0, z0); const float rhs = ((v%d + m) + kk) + lp[%u];\n"
+                              "      if (spec_local_near(live, a, rhs)) { const float t = spec_sphere_v<FAST>(lp + %u, a, tiny); %s\n"
+                              "        spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s; }\n",
+                              off, a, off + 3u, off, counted, (unsigned)i, a, w, apply_open, apply_close);
+                r += line;
+                if (bit_if_single) {
+                    std::snprintf(line, sizeof line, "      else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(a) - rhs) * 0.5f);\n", bit_if_single);
+                    r += line;
+                }
+            } else {
+                std::snprintf(line, sizeof line, "      const float t = spec_sphere<FAST>(lp + %u, x0, y0, z0, tiny); %s\n"
+                              "      spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s;\n", off, counted, (unsigned)i, a, w, apply_open, apply_close);
+                r += line;
+            }
+        } else {
+            if (test) {
+                std::snprintf(line, sizeof line,
+                              "      const SpecBox b = spec_box_a(lp + %u, x0, y0, z0); const float rhs = (v%d + m) + kk;\n"
+                              "      if (spec_local_box_near(live, b.a, rhs)) { const float t = spec_box_v<FAST>(b, tiny); %s\n"
+                              "        spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s; }\n",
+                              off, a, counted, (unsigned)i, a, w, apply_open, apply_close);
+                r += line;
+                if (bit_if_single) {
+                    std::snprintf(line, sizeof line, "      else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(b.a) - rhs) * 0.5f);\n", bit_if_single);
+                    r += line;
+                }
+            } else {
+                std::snprintf(line, sizeof line, "      const float t = spec_box<FAST>(lp + %u, x0, y0, z0, tiny); %s\n"
+                              "      spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s;\n", off, counted, (unsigned)i, a, w, apply_open, apply_close);
+                r += line;
+            }
+        }
+        r += "    }\n";
+    };
+    // the same member in a cached evaluation: no test; a lane whose restart is this leaf starts its accumulator here
+    auto cached_member = [&](size_t i, int a, int w) {
+        const RmLeafUse use = rm_leaf_use(rec, i);
+        const uint32_t kind = RM_OP_KIND(rec[i].op);
+        const unsigned off = (unsigned)i * 8u;
+        char applied[160];
+        if (use.k_rec >= 0) std::snprintf(applied, sizeof applied, "spec_smooth_union(lp + %u, v%d, t, live)", (unsigned)use.k_rec * 8u, a);
+        else std::snprintf(applied, sizeof applied, "vmin(v%d, t)", a);
+        std::snprintf(line, sizeof line, "      { const float t = %s<FAST>(lp + %u, x0, y0, z0, tiny); %sv%d = jstar == %uu ? t : %s; }\n",
+                      kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, counted, w, (unsigned)i, applied);
+        c += line;
+    };
+    int nv = 0, acc = -1;
+    for (size_t ui = 0; ui < units.size(); ui++) {
+        const BlendUnit& u = units[ui];
+        const unsigned long long bit = 1ull << ui;
+        const unsigned off = (unsigned)u.first * 8u;
+        const uint32_t kind = RM_OP_KIND(rec[(size_t)u.first].op);
+        if (u.kind == BU_START) {
+            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>" : "spec_cylinder<FAST>";
+            acc = nv++;
+            std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, x0, y0, z0, tiny); %s\n", acc, fn, off, counted);
+            r += line;
+            std::snprintf(line, sizeof line, "    float v%d = __uint_as_float(0x7F800000u);\n    if (!(skip & 0x%llxull)) { v%d = %s(lp + %u, x0, y0, z0, tiny); %s}\n",
+                          acc, bit, acc, fn, off, counted);
+            c += line;
+        } else if (u.kind == BU_SINGLE) {
+            const int w = nv++;
+            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, acc);
+            r += line;
+            refresh_member((size_t)u.first, acc, w, true, bit);
+            std::snprintf(line, sizeof line, "    float v%d = v%d;\n    if (!(skip & 0x%llxull))\n", w, acc, bit);
+            c += line;
+            cached_member((size_t)u.first, acc, w);
+            acc = w;
+            barrier(r); barrier(c);
+        } else if (u.kind == BU_PAIR) {
+            const int g = pair_index[u.first];
+            const int w1 = nv++, w2 = nv++;
+            std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n    { const float rhs = (v%d + m) + kr%d;\n    if (spec_local_near(live, pa%d, rhs)) {\n",
+                          w1, acc, w2, acc, acc, g, g);
+            r += line;
+            refresh_member((size_t)u.first, acc, w1, leaf_tests == 1, 0ull);
+            std::snprintf(line, sizeof line, "    v%d = v%d;\n", w2, w1);
+            r += line;
+            refresh_member((size_t)u.second, w1, w2, leaf_tests == 1, 0ull);
+            std::snprintf(line, sizeof line, "    } else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(pa%d) - rhs) * 0.5f); }\n", bit, g);
+            r += line;
+            std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n    if (!(skip & 0x%llxull)) {\n", w1, acc, w2, acc, bit);
+            c += line;
+            cached_member((size_t)u.first, acc, w1);
+            cached_member((size_t)u.second, w1, w2);
+            c += "    }\n";
+            acc = w2;
+            barrier(r); barrier(r); barrier(c); barrier(c);
+        } else if (u.kind == BU_SUB) {
+            // max(acc, -v) = acc while v + acc >= 0: outside the leaf (v > 0) with acc >= 0 is what the test establishes; the
+            // slack of that is the smaller of the two
+            const int w = nv++;
+            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, acc);
+            r += line;
+            if (kind == RM_KIND_SPHERE)
+                std::snprintf(line, sizeof line,
+                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) { v%d = vmax_negb(v%d, spec_sphere_v<FAST>(lp + %u, a, tiny)); %s}\n"
+                              "      else spec_cache_far(cache, live, 0x%llxull, fmin_(sqrt_lo(a) - lp[%u], v%d) - m); }\n",
+                              off, off, acc, w, acc, off, counted, bit, off + 4u, acc);
+            else
+                std::snprintf(line, sizeof line,
+                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
+                              "      if (spec_sub_box_near(live, b.a, v%d)) { v%d = vmax_negb(v%d, spec_box_v<FAST>(b, tiny)); %s}\n"
+                              "      else spec_cache_far(cache, live, 0x%llxull, fmin_(sqrt_lo(b.a), v%d) - m); }\n",
+                              off, acc, w, acc, counted, bit, acc);
+            r += line;
+            std::snprintf(line, sizeof line, "    float v%d = v%d;\n    if (!(skip & 0x%llxull)) { v%d = vmax_negb(v%d, %s<FAST>(lp + %u, x0, y0, z0, tiny)); %s}\n",
+                          w, acc, bit, w, acc, kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, counted);
+            c += line;
+            acc = w;
+            barrier(r); barrier(c);
+        } else {  // BU_GENERIC: evaluated as it stands; skipped in a cached evaluation only when it is dead (in front of every restart)
+            char pfx[32], accname[32];
+            std::snprintf(pfx, sizeof pfx, "g%d_", (int)ui);
+            std::snprintf(accname, sizeof accname, "v%d", acc);
+            const int w = nv++;
+            for (int which = 0; which < 2; which++) {
+                std::string& s = which ? c : r;
+                std::vector<std::string> st;
+                st.push_back(accname);
+                std::snprintf(line, sizeof line, which ? "    float v%d = v%d;\n    if (!(skip & 0x%llxull)) {\n" : "    float v%d = v%d;\n    {\n", w, acc, bit);
+                s += line;
+                if (!emit_plain_records(rec, u.first, u.last, st, pfx, counted, s) || st.size() != 1) return false;
+                std::snprintf(line, sizeof line, "    v%d = %s;\n    }\n", w, st.back().c_str());
+                s += line;
+            }
+            acc = w;
+            barrier(r); barrier(c);
+        }
+    }
+    // units in front of every live lane's restart are dead (one comparison each, in order, until one is alive)
+    r += "    cache.budget = fmin_(cache.budget, rbud);\n";
+    std::string tail;
+    int opened = 0;
+    for (size_t ui = 0; ui + 1 < units.size(); ui++) {  // the last unit holds the last possible restart: never dead
+        std::snprintf(line, sizeof line, "    if ((__builtin_amdgcn_ballot_w64(cache.jstar <= %uu) & live) == 0ull) { cache.skip |= 0x%llxull;\n", (unsigned)units[ui].last, 1ull << ui);
+        tail += line;
+        opened++;
+    }
+    for (int k = 0; k < opened; k++) tail += "}";
+    r += tail + "\n";
+    std::snprintf(line, sizeof line, "    return v%d;\n}\n", acc);
+    r += line;
+    c += line;
+    // map_scene_spec (one-position taps, should the four-tap function not be generated): the refresh without its book-keeping
+    r += "template <bool FAST>\nRM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n"
+         "    SpecCache unused;\n    return map_scene_refresh<FAST>(lp, qx, qy, qz, thr, live, tiny, n_eval, unused);\n}\n}  // namespace rmk\n";
+    c += "}  // namespace rmk\n";
+    *out = r + c;
+    return true;
+}
+
+
 // The material walk of a tagged program (rm_interp.h map_scene_material) as straight-line code: one evaluation of the
 // program WITH its Material tags at the position of a hit, every value a (distance, index) pair of named variables --
 // no stack in LDS, no decode.  Distances go through the operations map_scene_material applies (the interpreter's leaf
@@ -947,7 +1250,10 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     const bool materials = !mrec.empty();
     const bool prune = prune_kind == PRUNE_LATTICE, blend = prune_kind == PRUNE_BLEND;
     std::string body, taps, walk;
-    if (!(blend ? generate_map_scene_blend(rec, &body) : generate_map_scene(rec, prune, &body))) return false;
+    // programs that blend: skip sets carried along the ray where the top level is a chain (generate_blend_cached), else the
+    // local rule tested at every evaluation
+    const bool cached = blend && jit_knob("RM_JIT_CACHED", 1) != 0 && generate_blend_cached(rec, &body);
+    if (!cached && !(blend ? generate_map_scene_blend(rec, &body) : generate_map_scene(rec, prune, &body))) return false;
     const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
     if (walk_generated) *walk_generated = walk_spec;
     const char* taps_knob = std::getenv("RM_JIT_TAPS4");  // A/B: RM_JIT_TAPS4=0 keeps the taps on map_scene_spec
@@ -962,6 +1268,8 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     s += "#define RM_JIT_TU 1\n";
     if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
     if (blend) s += "#define RM_JIT_BLEND_PRUNE 1\n";
+    if (cached) s += "#define RM_JIT_CACHED 1\n";
+    if (cached && jit_knob("RM_JIT_PRUNE_STATS", 0) == 5) s += "#define RM_JIT_COUNT_REFRESH 1\n";
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
     if (structure_allows_bound_walk(rec)) s += "#define RM_JIT_BOUND_WALK 1\n";
@@ -1001,8 +1309,13 @@ inline uint64_t fnv1a(const char* p, size_t n, uint64_t h = 1469598103934665603u
     return h;
 }
 inline const char* const* compile_options(int* n) {
-    // the flags of the offline build (build.py HIP_FLAGS) that affect code generation
-    static const char* const opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
+    // the flags of the offline build (build.py HIP_FLAGS) that affect code generation.  RM_JIT_OPT_LEVEL (diagnostics, read once):
+    // another -O level
+    static const char* level = [] {
+        const char* v = std::getenv("RM_JIT_OPT_LEVEL");
+        return v && std::strlen(v) == 1 && std::strchr("0123s", v[0]) ? (v[0] == '0' ? "-O0" : v[0] == '1' ? "-O1" : v[0] == '2' ? "-O2" : v[0] == 's' ? "-Os" : "-O3") : "-O3";
+    }();
+    static const char* const opts[] = {"--offload-arch=gfx950", level, "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize"};
     *n = (int)(sizeof opts / sizeof *opts);
     return opts;
 }
@@ -1147,7 +1460,7 @@ public:
     std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune) {
         // a tagged program's kernel also depends on where its tags sit (the material walk is generated from mrec), and on the
         // A/B knobs of the generator as the environment holds them now (so that a process may compare two settings)
-        static const char* const knobs[] = {"RM_JIT_BLEND_LEAF_TESTS", "RM_JIT_BLEND_UPFRONT", "RM_JIT_GUARD_FENCE", "RM_JIT_LEAF_TESTS", "RM_JIT_MATERIAL_WALK",
+        static const char* const knobs[] = {"RM_JIT_BLEND_LEAF_TESTS", "RM_JIT_BLEND_UPFRONT", "RM_JIT_CACHED", "RM_JIT_CACHED_MIN_UNITS", "RM_JIT_GUARD_FENCE", "RM_JIT_LEAF_TESTS", "RM_JIT_MATERIAL_WALK",
                                             "RM_JIT_PRIO_LONG_RAYS", "RM_JIT_PRUNE_STATS", "RM_JIT_SCHED_BARRIER", "RM_JIT_SCHED_BARRIER_TAPS",
                                             "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU"};
         std::string knob_key;

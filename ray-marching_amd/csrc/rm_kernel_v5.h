@@ -90,7 +90,7 @@ RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, uns
 constexpr float kPruneAbs = 4.0e-6f;
 // The thresholds are kept (a register per ray, |sd| of a hit in its hit-buffer entry) by the generated kernels compiled
 // with pruning and by the library's interpreter kernels, whose chain loop prunes too (rm_interp.h map_scene_chain_pruned)
-#if defined(RM_JIT_PRUNE_ON) || !defined(RM_JIT_TU)
+#if defined(RM_JIT_PRUNE_ON) || defined(RM_JIT_CACHED) || !defined(RM_JIT_TU)
 #define RM_PRUNE_PLUMBING 1
 #endif
 // "is the leaf near for ANY live lane": the wave mask of the comparison itself (one v_cmp writing a scalar pair),
@@ -192,6 +192,64 @@ RM_DEV bool spec_local_near4(unsigned long long live, float a, const float (&rhs
 }
 // the blend radius as the rule uses it: a SmoothUnion with k <= 0 is a plain min
 RM_DEV float spec_local_k(LdsF r) { return fmax_(r[0], 0.0f); }
+
+// ---- Skip sets carried ALONG a ray (generated kernels compiled with RM_JIT_CACHED) ---------------------------------------
+// Every skipping rule above decides, at one position, from quantities that are 1-Lipschitz along the ray: leaf values and
+// their lower bounds, the accumulators a chain blends them into (min, max(a, -b), max, smin_k of 1-Lipschitz operands; a
+// Plane with |n| > 1 is not, programs with a Plane are not compiled this way), the scene value behind `thr`.  A march
+// only moves a ray along its own half-line, |rd| <= 1: between the evaluation at distance sc_0 and a later one at sc_n
+// every such quantity changes by at most (sc_n - sc_0) + 2E (E: the evaluation error, inside the margin m the caller adds
+// to `thr`).  So a decision taken at sc_0 with SLACK to spare stays true while the ray has not used the slack up:
+//   REFRESH  an evaluation with all tests (map_scene_spec).  It also returns, for the wave, the set of units it skipped
+//            for every live lane -- `skip`, one bit per unit (pair, leaf, segment) --, and per lane the smallest slack of
+//            those decisions, as a distance budget;
+//   CACHED   the evaluations that follow (map_scene_cached) run no test at all: a unit is evaluated iff its bit is clear.
+//            Valid for a lane while  sc_0 + budget > sc_n + thr_n  (two vector instructions per step); when that fails
+//            for any live lane, when a lane takes a new ray, or when the rays have come so much closer to the scene that
+//            a new look would skip more (thr halved for most lanes), the next evaluation is a refresh.
+// A unit is only put in the set if its slack covers `tau`, about one more step of the ray: otherwise it is simply evaluated.
+// Programs that blend also get RESTARTS from a refresh: at a Union / SmoothUnion of the top-level chain whose leaf is at
+// least k below the accumulator (v <= acc - k: the operator returns v, bit for bit: h = 0, min(acc, v) - 0 = v), everything
+// in front of that leaf is dead for the lane; `jstar` is the record of the last such leaf, and cached evaluations start the
+// lane's accumulator there (lanes whose restart lies further on compute garbage until they reach it).
+struct SpecCache {
+    unsigned long long skip = 0ull;  // wave-uniform
+    float budget = __uint_as_float(0x7F800000u);  // per lane: how far the ray may move before some decision could change
+    uint32_t jstar = 0u;             // per lane: record index of the lane's restart leaf, 0 = none
+    float tau = __uint_as_float(0x7F800000u);     // in, per lane: slack a decision needs to be worth remembering
+};
+// a unit that was skipped for every live lane: remember it if every live lane has slack to spare (half: the accumulator
+// and the leaf may each move against the decision)
+RM_DEV void spec_cache_far(SpecCache& c, unsigned long long live, unsigned long long bit, float half_slack) {
+    if ((__builtin_amdgcn_ballot_w64(!(half_slack > c.tau)) & live) == 0ull) {
+        c.skip |= bit;
+        c.budget = fmin_(c.budget, half_slack);  // (a NaN slack fails the test above)
+    }
+}
+// an evaluated Union / SmoothUnion member of the top-level chain as a restart: the leaf value v, the accumulator it meets
+RM_DEV void spec_cache_restart(SpecCache& c, uint32_t rec, float acc, float kk, float v, float& rbud) {
+    const float half = ((acc - kk) - v) * 0.5f;
+    const bool cand = half > c.tau;  // NaN: no
+    c.jstar = cand ? rec : c.jstar;
+    rbud = cand ? half : rbud;
+}
+// lower bound of a square root (for slacks: v_sqrt_f32 is within an ulp)
+RM_DEV float sqrt_lo(float a) { return __builtin_amdgcn_sqrtf(a) * 0.999999f; }
+template <bool FAST>
+RM_DEV float map_scene_cached(LdsF lp, float qx, float qy, float qz, unsigned long long skip, uint32_t jstar, unsigned long long live,
+                              SqrtGuard& tiny, uint32_t& n_eval);
+template <bool FAST>
+RM_DEV float map_scene_refresh(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval,
+                               SpecCache& cache);
+// largest value over the wave (all 64 lanes participate; lanes without a value pass 0)
+RM_DEV uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
 
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
@@ -681,6 +739,13 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u, hq_n = 0u;  // wave-uniform cursors: ready / miss / hit buffers
     uint32_t tap_t = TAP_IDLE, tap_n = 0u;                     // wave-uniform: tap phase step (TAP_IDLE = not in one), its entries
     bool pool_open = true;                                     // wave-uniform: the shared pool may still hold rays
+#ifdef RM_JIT_CACHED  // "Skip sets carried ALONG a ray"
+    unsigned long long cache_skip = 0ull;   // wave-uniform: units the last refresh skipped for every live lane
+    bool cache_valid = false;               // wave-uniform
+    float cache_gate = inf_f;               // wave-uniform: a refresh is due when most live lanes' thr_base fell below this
+    float cache_bs = -inf_f;                // per lane: sc at the refresh + the distance budget of its decisions
+    uint32_t cache_jstar = 0u;              // per lane: restart leaf (record index), 0 = none
+#endif
 
     auto flush_misses = [&]() {  // floor / black for every waiting ray that ended without a hit (<= 64): wgsl:117-130
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -751,6 +816,10 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                             it = shared ? 1u : 0u;
                             thr_base = shared ? __builtin_fabsf(f0) * 2.00002f : inf_f;
                             mode = M_MARCH;
+#ifdef RM_JIT_CACHED
+                            cache_bs = -inf_f;  // a new ray: nothing is known about it, the next evaluation is a refresh
+                            cache_jstar = 0u;
+#endif
                         }
                     }
                     rq_pos += n_want < avail ? n_want : avail;
@@ -863,7 +932,50 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             else __builtin_amdgcn_s_setprio(0);
         }
 #endif
+#ifdef RM_JIT_CACHED
+        float sd;
+        if (!tapping) {
+            // Is what the last refresh decided still good for every live lane (budget), and is it still worth using (the rays
+            // have not come so much closer that a new look would skip a lot more)?
+            const unsigned long long stale = __builtin_amdgcn_ballot_w64(!(cache_bs > sc + thr)) & live_m;  // NaN: stale
+            const uint32_t n_closer = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(thr_base < cache_gate) & live_m);
+            bool refresh = !cache_valid || stale != 0ull || 2u * n_closer > (uint32_t)__popcll(live_m);
+            sd = 0.0f;
+            if (!refresh) {
+                SqrtGuard tiny;
+                sd = map_scene_cached<true>(lprog_v, ex, ey, ez, cache_skip, cache_jstar, live_m, tiny, n_eval);
+                if (tiny.any_bad()) refresh = true;  // a square root outside the short form's range: the refresh has the generic one
+            }
+            if (refresh) {
+                asm volatile("");
+                SpecCache cache;
+                // worth remembering: decisions whose slack covers about one more step (thr_base is 2 |sd| of the step that led
+                // here) on top of the float margin
+                cache.tau = thr_base * 0.5f + thr;
+                SqrtGuard tiny;
+                sd = map_scene_refresh<true>(lprog_v, ex, ey, ez, thr, live_m, tiny, n_eval, cache);
+                if (tiny.any_bad()) {
+                    asm volatile("");
+                    SpecCache again;
+                    again.tau = cache.tau;
+                    sd = map_scene_refresh<false>(lprog_v, ex, ey, ez, thr, live_m, tiny, n_eval, again);
+                    cache = again;
+                }
+                cache_skip = cache.skip;
+                cache_jstar = cache.jstar;
+                cache_bs = sc + cache.budget;
+                cache_valid = true;
+                cache_gate = 0.5f * __uint_as_float(wave_max_u32(is_live && thr_base == thr_base ? __float_as_uint(thr_base) : 0u));
+#ifdef RM_JIT_COUNT_REFRESH  // statistics (RM_JIT_PRUNE_STATS=5): refreshes instead of leaves
+                n_eval += 1u;
+#endif
+            }
+        } else {
+            sd = eval_scene(ex, ey, ez, thr, live_m);
+        }
+#else
         const float sd = eval_scene(ex, ey, ez, thr, live_m);
+#endif
 
         if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
             const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);

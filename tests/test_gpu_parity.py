@@ -1026,7 +1026,7 @@ def test_draw_is_stream_capturable(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("form", ["generated", "generated_no_leaf_tests"])
+@pytest.mark.parametrize("form", ["generated", "leaf_tests", "tested_at_every_step", "tested_at_every_step_leaf_tests"])
 def test_local_skipping_rule_of_blending_programs(oracle, form):
     """Programs that blend skip a leaf (or a pair) whose lower bound is at least k above the accumulator it would be blended
     into, for every live lane (rm_groups.h, rm_kernel_v5.h spec_local_near): exact only if "at least k above" is decided on
@@ -1035,7 +1035,8 @@ def test_local_skipping_rule_of_blending_programs(oracle, form):
     of the previous accumulator (every one matters although all but the last are far above the final value), k = 0 / negative /
     1e-6 / larger than the scene, partners that coincide or are 40 units apart, everything 1000 units from the origin, Unions,
     Subtractions and an Intersection mixed into the chain -- and the parameters (k included, through zero) moving under ONE
-    compiled kernel."""
+    compiled kernel.  The default form also carries its decisions ALONG the ray (skip sets with a distance budget, restarts:
+    rm_kernel_v5.h): the staircases and the grazing views are where a budget runs out between two steps."""
     import math
     rng = np.random.default_rng(4242)
     W, H = 80, 56
@@ -1089,8 +1090,12 @@ def test_local_skipping_rule_of_blending_programs(oracle, form):
         r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
         r.set_option(_ffi.RM_OPT_PRUNE, 1)
         r.resize_command_buffer(4096)
-        if form == "generated_no_leaf_tests":
-            os.environ["RM_JIT_BLEND_LEAF_TESTS"] = "0"      # read when a structure is generated: pairs only, members untested
+        # knobs of the generator, read when a structure is generated (and part of the kernel cache's key): members of a near pair
+        # with a test of their own; no skip sets carried along the ray (every evaluation runs the tests)
+        if form.endswith("leaf_tests"):
+            os.environ["RM_JIT_BLEND_LEAF_TESTS"] = "1"
+        if form.startswith("tested_at_every_step"):
+            os.environ["RM_JIT_CACHED"] = "0"
         for offset in ((0.0, 0.0, 0.0), (800.0, -300.0, 500.0)):
             for kscale in (1.0, 0.0, -1.0):                  # the same structures again with every k scaled: same compiled kernels
                 for name, (nodes, root) in cases(offset, kscale).items():
@@ -1114,6 +1119,7 @@ def test_local_skipping_rule_of_blending_programs(oracle, form):
                                                          % (name, offset, kscale, events, lim, cull, len(bad), bad[:3].tolist()))
     finally:
         os.environ.pop("RM_JIT_BLEND_LEAF_TESTS", None)
+        os.environ.pop("RM_JIT_CACHED", None)
         r.close()
 
 
