@@ -1252,7 +1252,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     std::string body, taps, walk;
     // programs that blend: skip sets carried along the ray where the top level is a chain (generate_blend_cached), else the
     // local rule tested at every evaluation
-    const bool cached = blend && jit_knob("RM_JIT_CACHED", 1) != 0 && generate_blend_cached(rec, &body);
+    const bool cached = blend && jit_knob("RM_JIT_CACHED", 0) != 0 && generate_blend_cached(rec, &body);  // measured slower: off
     if (!cached && !(blend ? generate_map_scene_blend(rec, &body) : generate_map_scene(rec, prune, &body))) return false;
     const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
     if (walk_generated) *walk_generated = walk_spec;
