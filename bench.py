@@ -316,6 +316,22 @@ def run_rank(args):
     elapsed, draw_ms, kernel_ms = timed(F, headline_draw, unis)
     specialized = bool(res.info(_ffi.RM_INFO_SPECIALIZED))                    # what the LAST timed launch ran
     jit_ms = res.info(_ffi.RM_INFO_JIT_COMPILE_MS)
+    jit_from_cache = bool(res.info(_ffi.RM_INFO_JIT_FROM_CACHE))
+    # what the compiler takes for this structure when the on-disk cache of compiled kernels does not have it (the first time a
+    # structure is drawn on a machine): the same source through hipRTC with the cache switched off, untimed set-up
+    jit_cold_ms = None
+    if rank == 0 and specialized:
+        old_dir = os.environ.get("RM_JIT_CACHE_DIR")
+        os.environ["RM_JIT_CACHE_DIR"] = "off"
+        try:
+            rc_, jit_cold_ms, _, _ = renderer.jit_compile(cc, words, 4, prune=bool(res.info(_ffi.RM_INFO_PRUNED)))
+            if rc_ != _ffi.RM_OK:
+                jit_cold_ms = None
+        finally:
+            if old_dir is None:
+                del os.environ["RM_JIT_CACHE_DIR"]
+            else:
+                os.environ["RM_JIT_CACHE_DIR"] = old_dir
     last = (strips if tile else full)[(K - 1) % F]
     checksum = float(last[..., :3].double().sum().item())                     # touches the result: nothing was skipped
     # every in-flight buffer as the timed loop left it, with the uniforms of the last draw into it: `parity` (below) compares
@@ -441,7 +457,7 @@ def run_rank(args):
             legs["ab_interpreter_kernel"] = {
                 "kernel": "rm_render_v5 (interpreter: LDS-staged records; %s), one frame in flight"
                           % ["general record loop, accumulator machine", "stack-free chain loop",
-                             "stack-free chain loop, far pairs of primitives skipped"][min(loop, 2)],
+                             "stack-free chain loop over the records wave-level culling names", "tree loop, one dispatch per record"][min(loop, 3)],
                 "value": W * H * K / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
                 "same_image": float(full[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
             res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)
@@ -476,7 +492,8 @@ def run_rank(args):
                                    % (W, H, args.scene, cc, len(words), args.max_iter),
                        "step": "prepare (uniform write + command-buffer rewrite, renderer.rs:213-239) + draw, image resident in HBM",
                        "camera": args.camera, "kernel": args.kernel, "specialized_kernel": specialized,
-                       "jit_compile_ms": jit_ms, "frames_in_flight": F, "sharding": sharding,
+                       "jit_compile_ms": jit_ms, "jit_from_disk_cache": jit_from_cache, "jit_cold_compile_ms": jit_cold_ms,
+                       "frames_in_flight": F, "sharding": sharding,
                        "barrier_backend": barrier_backend, "barrier_group_world_size": group_world if world > 1 else None,
                        "barrier_fallback_reason": fallback_reason},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

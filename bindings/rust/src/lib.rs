@@ -100,6 +100,7 @@ pub const RM_INFO_JIT_STATE: c_int = 7;
 pub const RM_INFO_JIT_COMPILE_MS: c_int = 8;
 pub const RM_INFO_PRUNED: c_int = 9;
 pub const RM_INFO_INTERPRETER_LOOP: c_int = 10;
+pub const RM_INFO_JIT_FROM_CACHE: c_int = 11;
 
 // enum rm_program_fact: indices into the array rm_program_info fills
 pub const RM_PROGRAM_RECORDS: usize = 0;
@@ -159,6 +160,7 @@ extern "C" {
     pub fn rm_measure_write_bandwidth(ctx: *mut rm_ctx, bytes: u64, iters: c_int, out_gbps: *mut f64) -> c_int;
     pub fn rm_selftest_sqrt(ctx: *mut rm_ctx, out_mismatches: *mut u64, out_first_bad_bits: *mut u32) -> c_int;
     pub fn rm_selftest_ops(ctx: *mut rm_ctx, a: *const f32, b: *const f32, out: *mut f32, n: u32) -> c_int;
+    pub fn rm_selftest_wave(ctx: *mut rm_ctx, input: *const f32, n_waves: u32, out: *mut f32) -> c_int;
     pub fn rm_read_wave_stats(ctx: *mut rm_ctx, dst: *mut c_void, cap_bytes: u64, out_bytes: *mut u64) -> c_int;
     pub fn rm_jit_source(cmd_count: u32, words: *const u32, n_words: u32, waves_per_tile: c_int, buf: *mut c_char,
                          cap: usize, needed: *mut usize) -> c_int;

@@ -165,13 +165,17 @@ enum rm_info {
     RM_INFO_SPECIALIZED = 6,     /* 1 if the last march launch ran a structure-specialised kernel, else 0 */
     RM_INFO_JIT_STATE = 7,       /* specialisation of the current program: 0 none requested, 1 compiling, 2 ready, 3 failed
                                     (rm_jit_log has the reason) */
-    RM_INFO_JIT_COMPILE_MS = 8,  /* wall time hipRTC took for the current program's kernel; 0 until it is ready */
+    RM_INFO_JIT_COMPILE_MS = 8,  /* wall time hipRTC took for the current program's kernel -- or the read from the disk cache
+                                  * (RM_INFO_JIT_FROM_CACHE) --; 0 until it is ready */
     RM_INFO_PRUNED = 9,          /* which skipping rule the kernel requested for the current program carries (RM_OPT_PRUNE): 0 none,
-                                  * 1 far-primitive pruning on a threshold (min / max programs), 2 the local rule of programs that
-                                  * blend with SmoothUnion */
-    RM_INFO_INTERPRETER_LOOP = 10 /* record loop the interpreter kernels ran the program of the last march launch with: 0 the
+                                  * 1 far-primitive pruning on a threshold (min / max programs), 2 the rules of programs that blend
+                                  * with SmoothUnion along a top-level chain; both through wave-level culling */
+    RM_INFO_INTERPRETER_LOOP = 10, /* record loop the interpreter kernels ran the program of the last march launch with: 0 the
                                     general one (value stack, every node type; also reported when a specialised kernel ran), 1 the chain loop ("a op b op c ...": no
-                                    stack), 2 the chain loop with far pairs of primitives skipped (exact; the default for chains) */
+                                    stack), 2 the chain loop over the records wave-level culling names (exact; the default for chains staged in LDS), 3 the tree
+                                    loop (reference node types in any arrangement: one dispatch per record, right operands nobody needs stepped over) */
+    RM_INFO_JIT_FROM_CACHE = 11  /* 1 when the current program's kernel was read from the disk cache of compiled structures
+                                  * (RM_JIT_CACHE_DIR; default: jit_cache next to the library) instead of being compiled */
 };
 
 int rm_abi_version(void);
@@ -291,6 +295,10 @@ int rm_measure_write_bandwidth(rm_ctx* ctx, uint64_t bytes, int iters, double* o
  * generic sqrt(a), a / b, (float) i32(round(a)) -- compared on the host with the oracle's definitions. */
 int rm_selftest_sqrt(rm_ctx* ctx, uint64_t* out_mismatches, uint32_t* out_first_bad_bits);
 int rm_selftest_ops(rm_ctx* ctx, const float* a, const float* b, float* out, uint32_t n);
+/* The two cross-lane primitives of wave-level culling (DPP row operations), one wave per 64 inputs (non-negative floats, +inf,
+ * NaN): out[i] = the largest value of input i's wave (by bit pattern: a NaN wins), out[64 n_waves + i] = the minimum over the
+ * inputs of the LOWER lanes of its wave (+inf for lane 0; a NaN is skipped).  tests/test_gpu_arithmetic.py compares with numpy. */
+int rm_selftest_wave(rm_ctx* ctx, const float* in, uint32_t n_waves, float* out);
 
 /* Diagnostics: per-wave records of the last draw made with RM_OPT_WAVE_STATS = 1, four u64 per
  * wave in dispatch order: [0] start, [1] end (100 MHz s_memrealtime ticks), [2] tile id << 32 |

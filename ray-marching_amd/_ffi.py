@@ -40,7 +40,7 @@ RM_OPT_OUTPUT_FORMAT = 10
 RM_FORMAT_RGBA32F, RM_FORMAT_RGBA8_UNORM, RM_FORMAT_BGRA8_UNORM = 0, 1, 2
 RM_INFO_KERNEL_MS, RM_INFO_PROGRAM_COMMANDS, RM_INFO_PROGRAM_WORDS, RM_INFO_PROGRAM_DEPTH = 0, 1, 2, 3
 RM_INFO_DEVICE, RM_INFO_CU_COUNT, RM_INFO_SPECIALIZED, RM_INFO_JIT_STATE, RM_INFO_JIT_COMPILE_MS = 4, 5, 6, 7, 8
-RM_INFO_PRUNED, RM_INFO_INTERPRETER_LOOP = 9, 10
+RM_INFO_PRUNED, RM_INFO_INTERPRETER_LOOP, RM_INFO_JIT_FROM_CACHE = 9, 10, 11
 
 _hip = None
 _host = None
@@ -117,6 +117,8 @@ def hip_lib():
         L.rm_selftest_sqrt.restype = C.c_int
         L.rm_selftest_ops.argtypes = [vp, vp, vp, vp, u32]
         L.rm_selftest_ops.restype = C.c_int
+        L.rm_selftest_wave.argtypes = [vp, vp, u32, vp]
+        L.rm_selftest_wave.restype = C.c_int
         L.rm_read_wave_stats.argtypes = [vp, vp, u64, C.POINTER(u64)]
         L.rm_read_wave_stats.restype = C.c_int
         sz = C.c_size_t

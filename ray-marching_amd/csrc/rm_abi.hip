@@ -176,9 +176,9 @@ int ensure_program(rm_ctx* c, hipStream_t s) {
         c->cmd_status = rc;
         return fail(c, rc, "invalid CSG program in command buffer: %s", rm_status_string(rc));
     }
-    // the group records of a prunable program (RmDecoded::groups) follow its records in the same buffer
+    // the unit records of wave-level culling (RmDecoded::units) follow the program's records in the same buffer
     std::vector<RmRecord> image = d.rec;
-    image.insert(image.end(), d.groups.begin(), d.groups.end());
+    image.insert(image.end(), d.units.begin(), d.units.end());
     if (image.size() > c->d_prog_cap) {
         if (c->d_prog) (void)hipFree(c->d_prog);
         c->d_prog = nullptr;
@@ -258,8 +258,8 @@ int ensure_materials(rm_ctx* c, hipStream_t s) {
 int prune_kind(const RmDecoded& d, int option) {
     if (option == 0) return rmjit::PRUNE_NONE;
     static const uint32_t blend_leaves = std::getenv("RM_BLEND_PRUNE_LEAVES") ? (uint32_t)std::atoi(std::getenv("RM_BLEND_PRUNE_LEAVES")) : kBlendPruneLeaves;
-    if (d.prunable && (option == 1 || d.n_leaves >= kPruneLeaves)) return rmjit::PRUNE_LATTICE;
-    if (d.blend_prunable && (option == 1 || d.n_leaves >= blend_leaves)) return rmjit::PRUNE_BLEND;
+    if (d.unit_mode == RM_UNITS_LATTICE && (option == 1 || d.n_leaves >= kPruneLeaves)) return rmjit::PRUNE_LATTICE;
+    if (d.unit_mode == RM_UNITS_BLEND && (option == 1 || d.n_leaves >= blend_leaves)) return rmjit::PRUNE_BLEND;
     return rmjit::PRUNE_NONE;
 }
 
@@ -366,9 +366,17 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // 0 the general record loop, 1 the chain loop, 2 the chain loop with far pairs skipped (default)
     static const int chain_mode = std::getenv("RM_CHAIN_MODE") ? std::atoi(std::getenv("RM_CHAIN_MODE")) : 2;
     const bool chain = c->decoded.is_chain && chain_mode > 0;
-    const bool chain_groups = chain && c->decoded.prunable && c->decoded.groups.size() == c->decoded.rec.size() / 2u;
-    L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (chain_groups && chain_mode >= 2 ? 8u : 0u);
-    c->last_loop = (L.flags & 8u) ? 2 : (L.flags & 4u) ? 1 : 0;
+    // ... and whether the interpreter uses the wave-level culling mask (bit 3): 2 (default) yes, wherever the program has units
+    // Measured (profiles/r03_interpreter_loops.txt): over a chain the mask names the records to fetch at all -- 64-node scene at 4K
+    // 15.5 -> 5.3 ms, metric scene 1.23 -> 0.71 ms --, but it has a fixed price per evaluation (~250 cycles) that four leaves
+    // do not repay (8-node scene 0.44 -> 0.66 ms), and in the tree and general loops, where a skipped record is still fetched
+    // and decoded, it loses (balanced 32-node tree 1.85 -> 2.32 ms, the blended scene 4.0 -> 4.4): chains of a dozen leaves or more.
+    const bool units = c->decoded.unit_mode == RM_UNITS_LATTICE && chain && chain_mode >= 2 && c->decoded.n_leaves >= kPruneLeaves;
+    // bit 4: tree program (every record one of the eight fast shapes): the interpreter's one-dispatch-per-record loop.  RM_CHAIN_MODE=0
+    // keeps the general loop for everything (diagnostics)
+    const bool tree = c->decoded.is_tree && chain_mode > 0;
+    L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (units ? 8u : 0u) | (tree ? 16u : 0u);
+    c->last_loop = (L.flags & 4u) ? (((L.flags & 8u) && lds) ? 2 : 1) : (tree && !c->decoded.has_extensions) ? 3 : 0;  // (the scalar-cache variant has no unit records at hand)
     // programs that blend: a ray the plain miss tests cannot clear (every bound is inflated by the blend radius) gets the
     // program run on lower bounds of its leaves along the ray.  RM_BOUND_WALK=0 (diagnostics) keeps the plain tests only.
     static const bool bound_walk_on = !(std::getenv("RM_BOUND_WALK") && std::atoi(std::getenv("RM_BOUND_WALK")) == 0);
@@ -425,8 +433,9 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     dim3 grid(n_wg, 1, n_frames);
     if (int rc = ensure_stats(c, L, (size_t)n_wg * n_frames * WPT)) return rc;
     if (int rc = time_begin(c, s)) return rc;
-    // reference-only programs run the lean interpreter; extension node types select the wider one
-    const bool ext = c->decoded.has_extensions;
+    // reference-only programs run the lean interpreter (chain and tree loops only); extension node types select the wider one,
+    // which has the general record loop (RM_CHAIN_MODE=0, diagnostics: everything takes that one)
+    const bool ext = c->decoded.has_extensions || !c->decoded.is_tree || chain_mode == 0;
     c->last_specialized = spec_fn != nullptr;
     // When a wave takes new rays.  With far-primitive pruning every evaluation tests which primitives are near for ANY lane:
     // lanes at unrelated march depths (a lane refilled the moment it retires) keep most of them near, while 64 rays started
@@ -436,7 +445,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // lanes cost (8-node scene -17 %, the blended scene -2 %), so those kernels keep refilling lane by lane.
     static const bool blend_in_step = !(std::getenv("RM_BLEND_IN_STEP") && std::atoi(std::getenv("RM_BLEND_IN_STEP")) == 0);  // A/B
     const bool pruning = spec_fn ? (c->spec && (c->spec_pruned == rmjit::PRUNE_LATTICE || (c->spec_pruned == rmjit::PRUNE_BLEND && blend_in_step)))
-                                 : (L.flags & 8u) != 0u;
+                                 : ((L.flags & 8u) != 0u && lds);
     const uint32_t refill_auto = c->refill_min_v5 != 0u ? c->refill_min_v5 : (pruning ? 64u : 1u);
     if (spec_fn) {
         uint32_t n_tiles_arg = n_tiles, refill = refill_auto;
@@ -488,7 +497,9 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.strip_rows = strips.rows; L.strip_first = strips.first; L.strip_stride = strips.stride;
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
-    L.n_grp = (uint32_t)c->decoded.groups.size();
+    L.n_grp = (uint32_t)c->decoded.units.size();
+    L.unit_mode = c->decoded.unit_mode;
+    L.unit_kmax = c->decoded.unit_kmax;
     L.value_spill_depth = c->decoded.spill_depth;
     L.spill_depth = c->decoded.spill_depth + 3u * c->decoded.xform_depth;  // saved positions follow the value stack
     L.bounds = c->decoded.has_xforms ? c->d_bounds : nullptr;
@@ -801,7 +812,7 @@ RM_EXPORT int rm_program_info(uint32_t cmd_count, const uint32_t* words, uint32_
     if (rc != RM_OK) return rc;
     uint32_t subtracted = 0u;
     for (const RmRecord& r : d.rec) subtracted += (r.op & RM_OP_NOCULL) != 0u;
-    const uint32_t facts[RM_PROGRAM_FACTS] = {(uint32_t)d.rec.size(), d.n_sphere, d.n_box, subtracted, (uint32_t)d.groups.size(), d.spill_depth,
+    const uint32_t facts[RM_PROGRAM_FACTS] = {(uint32_t)d.rec.size(), d.n_sphere, d.n_box, subtracted, (uint32_t)d.units.size(), d.spill_depth,
                                               d.is_chain ? 1u : 0u, d.prunable ? 1u : 0u, d.bound_walk ? 1u : 0u, d.has_xforms ? 1u : 0u,
                                               d.n_leaves, (uint32_t)prune_kind(d, 2)};
     for (uint32_t i = 0; out && i < n_out && i < (uint32_t)RM_PROGRAM_FACTS; i++) out[i] = facts[i];
@@ -1054,11 +1065,13 @@ RM_EXPORT int rm_get_info(rm_ctx* c, int key, double* out) {
     case RM_INFO_INTERPRETER_LOOP: *out = c->last_specialized ? 0.0 : (double)c->last_loop; return RM_OK;
     case RM_INFO_PRUNED: *out = c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty ? (double)c->spec_pruned : 0.0; return RM_OK;
     case RM_INFO_JIT_STATE:
+    case RM_INFO_JIT_FROM_CACHE:
     case RM_INFO_JIT_COMPILE_MS: {
         *out = 0.0;
         if (c->spec && c->spec_gen == c->prog_gen && !c->cmd_dirty) {
             std::lock_guard<std::mutex> lk(c->spec->m);
             if (key == RM_INFO_JIT_STATE) *out = 1.0 + (double)c->spec->state;
+            else if (key == RM_INFO_JIT_FROM_CACHE) *out = c->spec->from_cache ? 1.0 : 0.0;
             else *out = c->spec->compile_ms;
         }
         return RM_OK;
@@ -1130,6 +1143,25 @@ RM_EXPORT int rm_selftest_ops(rm_ctx* c, const float* a, const float* b, float* 
     return RM_OK;
 }
 
+RM_EXPORT int rm_selftest_wave(rm_ctx* c, const float* in, uint32_t n_waves, float* out) {
+    if (!c) return RM_ERR_NULL;
+    if (!in || !out || n_waves == 0u || n_waves > 65535u) return fail(c, RM_ERR_NULL, "rm_selftest_wave: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = (size_t)n_waves * 64u;
+    float *din = nullptr, *dout = nullptr;
+    HIP_TRY(c, hipMalloc(&din, n * 4));
+    HIP_TRY(c, hipMalloc(&dout, n * 8));
+    hipError_t e = hipMemcpy(din, in, n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rmk::rm_selftest_wave_kernel, dim3(n_waves), dim3(64), 0, c->stream, din, dout, n_waves);
+        e = hipStreamSynchronize(c->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dout, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(din); (void)hipFree(dout);
+    if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "rm_selftest_wave: %s", hipGetErrorString(e));
+    return RM_OK;
+}
+
 RM_EXPORT int rm_measure_write_bandwidth(rm_ctx* c, uint64_t bytes, int iters, double* out_gbps) {
     if (!c) return RM_ERR_NULL;
     if (!out_gbps) return fail(c, RM_ERR_NULL, "rm_measure_write_bandwidth: out is NULL");
@@ -1159,7 +1191,7 @@ int jit_decode(uint32_t cmd_count, const uint32_t* words, uint32_t n_words, int 
     RmDecoded d;
     int rc = rm_decode_program(cmd_count, words, n_words, &d);
     if (rc != RM_OK) return rc;
-    const int kind = !prune ? rmjit::PRUNE_NONE : d.prunable ? rmjit::PRUNE_LATTICE : d.blend_prunable ? rmjit::PRUNE_BLEND : rmjit::PRUNE_NONE;
+    const int kind = !prune ? rmjit::PRUNE_NONE : d.unit_mode == RM_UNITS_LATTICE ? rmjit::PRUNE_LATTICE : d.unit_mode == RM_UNITS_BLEND ? rmjit::PRUNE_BLEND : rmjit::PRUNE_NONE;
     if (!rmjit::can_specialise(d.rec) || !rmjit::generate_source(d.rec, d.mrec, wpt, kind, src)) return RM_ERR_ARG;
     return RM_OK;
 }

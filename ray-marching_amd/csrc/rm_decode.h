@@ -9,7 +9,7 @@
 #include <vector>
 
 #include "rm_device.h"
-#include "rm_groups.h"
+#include "rm_units.h"
 
 struct RmDecoded {
     std::vector<RmRecord> rec;
@@ -40,27 +40,31 @@ struct RmDecoded {
     // Chain program: record 0 pushes a sphere / box, every later record is a sphere / box fused with a Union / Subtraction
     // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
     bool is_chain = false;
+    // Tree program: every record is one of the eight shapes of RM_OP_FASTCLASS (spheres, boxes, Union, Subtraction in any
+    // arrangement): the interpreter kernels run it through map_scene_tree.  With unit records (unit_mode RM_UNITS_LATTICE) a pushed
+    // leaf that starts the right operand of a Union / Subtraction also says how to step over that whole operand when none of
+    // its leaves is needed -- min(a, +inf) and max(a, -inf) leave a alone --: the unit record's p[4], as an integer,
+    // records | leaves << 16 | 1 << 24 (0: not such a leaf).
+    bool is_tree = false;
     // The miss test of a ray can run the program on lower bounds (rm_kernel_v5.h "Miss test on lower bounds"): the program
     // blends with SmoothUnion, holds a Plane the tables cannot clear, or an Intersection (otherwise the plain tests are as
     // sharp), its leaves
     // are in world space (no transforms), and the accumulator machine never holds more than one spilled value
     bool bound_walk = false;
-    // Grouped far tests (prunable programs): one bounding sphere per pair of consecutive sphere / box leaves, in
-    // program order (pair g = pruned leaves 2g and 2g + 1; an odd last leaf stays alone).  Which leaves pair up depends
-    // on the structure only -- the generated code is compiled per structure -- the spheres on the parameters:
-    // p[0..2] centre, p[3] = p[4] = R' * 1.000005 rounded up (what spec_group_near reads), where
-    //   R' = (R + 2e-6 (|c|_1 + R)) (1 + 1e-6),  R = max_i (|c_i - c| + rho_i)   (rho: radius / half-diagonal)
-    // covers a member's own evaluation error: a member's value at p is >= |p - c| - R in real arithmetic (triangle
-    // inequality; a box's distance is at least the distance to its bounding sphere), and its computed value differs
-    // from that by at most ~4e-7 of |p|_1 + |c_i|_1 + rho_i -- near the group, where the test matters, that is within
-    // the 2e-6 (|c|_1 + R) added here plus the factor 1.000005 applied to thr + R' by the test.
-    std::vector<RmRecord> groups;
-    // The LOCAL skipping rule of programs that blend (rm_groups.h): prunable is false for them (SmoothUnion is not a lattice
-    // operator), `groups` then holds one record per pair of rm_blend_pairs(), in that order, with
-    //   p[3] = p[4] = (k + R') * 1.000005 rounded up,  k = the larger blend radius of the two operators (0 for a Union)
-    // -- what the test adds to the accumulator: a member's value is >= |p - c| - R', so |p - c| >= acc + k + R' (plus the
-    // float margin the test adds) puts both members at least k above the accumulator.
-    bool blend_prunable = false;
+    // Wave-level culling (rm_kernel_v5.h; which records form a unit: rm_units.h): one record per unit, in unit order, behind the
+    // program in device memory and in LDS.  A unit stands for a leaf (p[0..2] its centre) bounded from both sides:
+    //   p[3]  outer radius R' * 1.000005 rounded up:  value(q) >= |q - c| - p[3]    (+inf for an opaque unit)
+    //         R' = (R + 2e-6 (|c|_1 + R)) (1 + 1e-6),  R: sphere max(r, 0), box |max(h, 0)|, cylinder |(max(r,0), max(hh,0))|
+    //         -- the slack covers the leaf's own evaluation error near the unit (~4e-7 of |q|_1 + |c|_1 + R) and the rounding of c
+    //   p[4]  inner radius, rounded down:             value(q) <= |q - c| - p[4]    (-inf for an opaque unit)
+    //         sphere r, box min h, cylinder min(r, hh); with a negative size in it, minus the sum of the absolute sizes
+    //   p[5]  the blend radius of the unit's SmoothUnion, max(k, 0); 0 for every other unit
+    //   p[6]  the unit's kind (RM_UNIT_*), as an integer
+    // unit_mode: RM_UNITS_LATTICE (prunable programs), RM_UNITS_BLEND (programs that blend whose top level is a chain), or
+    // RM_UNITS_NONE -- also when there are more than 64 units.  unit_kmax: the largest p[5].
+    std::vector<RmRecord> units;
+    uint32_t unit_mode = RM_UNITS_NONE;
+    float unit_kmax = 0.0f;
     // Space transformations (extension): deepest nesting, and -- because a transformed primitive's parameters no longer
     // say where it is -- one world-space bounding sphere (x, y, z, radius) per bounded primitive for the miss tests.
     // cull_veto: some transform is not a similarity (non-unit quaternion, scale not positive and finite): no culling.
@@ -253,6 +257,7 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
                 if (depth > 32) return RM_ERR_STACK_OVERFLOW;
                 if (depth > d.max_depth) d.max_depth = depth;
                 r.op = RM_OP(kind, RM_MODE_PUSH, spill);
+                if (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX) r.op |= (kind == RM_KIND_SPHERE ? 5u : 6u) << 16;  // RM_OP_FASTCLASS
             }
             d.rec.push_back(r);
         } else if (op == RM_CMD_UNION || op == RM_CMD_SUBTRACTION || op == RM_CMD_INTERSECTION ||
@@ -274,6 +279,7 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             depth--;
             spilled--;
             r.op = RM_OP(RM_KIND_POP, mode, 0);
+            if (mode == RM_MODE_UNION || mode == RM_MODE_SUB) r.op |= (mode == RM_MODE_UNION ? 7u : 8u) << 16;  // RM_OP_FASTCLASS
             d.rec.push_back(r);
         } else {
             return RM_ERR_OPCODE;
@@ -304,55 +310,90 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         }
     }
     for (const RmRecord& r : d.rec) d.n_leaves += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
-    // bounding sphere of two sphere / box leaves as a group record; `extra` is added to the radius the tests read
-    auto pair_record = [](const RmRecord& m0, const RmRecord& m1, double extra) {
-            const RmRecord* m[2] = {&m0, &m1};
-            double c[3], R = 0.0;
-            for (int k = 0; k < 3; k++) c[k] = 0.5 * ((double)m[0]->p[k] + (double)m[1]->p[k]);
-            for (int i = 0; i < 2; i++) {
-                const RmRecord& q = *m[i];
-                const double rho = RM_OP_KIND(q.op) == RM_KIND_SPHERE ? std::fmax((double)q.p[3], 0.0)
-                                 : std::sqrt(std::pow(std::fmax((double)q.p[3], 0.0), 2) + std::pow(std::fmax((double)q.p[4], 0.0), 2) +
-                                             std::pow(std::fmax((double)q.p[5], 0.0), 2));
-                const double dist = std::sqrt(std::pow(q.p[0] - c[0], 2) + std::pow(q.p[1] - c[1], 2) + std::pow(q.p[2] - c[2], 2)) + rho;
-                R = dist > R || dist != dist ? dist : R;  // a NaN sticks: the group is then never far
-            }
-            R = (R + 2.0e-6 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + R)) * (1.0 + 1.0e-6);
+    {   // unit records, see RmDecoded::units
+        std::vector<RmUnit> us;
+        if (d.prunable && rm_lattice_units(d.rec, &us)) d.unit_mode = RM_UNITS_LATTICE;
+        else if (!d.prunable && !d.has_xforms && rm_has_blend(d.rec) && rm_blend_units(d.rec, &us)) d.unit_mode = RM_UNITS_BLEND;
+        const float inf = INFINITY;
+        for (size_t ui = 0; ui < us.size(); ui++)  // RM_OP_UNIT: which unit guards a record
+            for (int k = us[ui].first; k <= us[ui].last; k++) d.rec[(size_t)k].op |= (uint32_t)(ui + 1u) << 8;
+        for (const RmUnit& u : us) {
             RmRecord g;
             std::memset(&g, 0, sizeof g);
             g.op = RM_OP(RM_KIND_SPHERE, RM_MODE_PUSH, 0);
-            // the centre is rounded to binary32: its displacement (<= an ulp of |c|) is inside the 2e-6 |c|_1 slack
-            g.p[0] = (float)c[0]; g.p[1] = (float)c[1]; g.p[2] = (float)c[2];
-            // p[3] = p[4] = R' * 1.000005 rounded up: the one radius the test reads, next to the centre (one 16-byte read)
-            g.p[4] = std::nextafterf((float)(((double)std::nextafterf((float)R, INFINITY) + extra) * 1.000005), INFINITY);
-            g.p[3] = g.p[4];
-            return g;
-    };
-    if (d.prunable) {  // group spheres, see RmDecoded::groups
-        const RmRecord* first = nullptr;
-        for (const RmRecord& r : d.rec) {
-            const uint32_t kind = RM_OP_KIND(r.op);
-            if (kind != RM_KIND_SPHERE && kind != RM_KIND_BOX) continue;
-            if (!first) { first = &r; continue; }
-            d.groups.push_back(pair_record(*first, r, 0.0));
-            first = nullptr;
+            std::memcpy(&g.p[6], &u.kind, 4);
+            if (u.leaf < 0) {
+                g.p[3] = inf;
+                g.p[4] = -inf;
+            } else {
+                const RmRecord& q = d.rec[(size_t)u.leaf];
+                const uint32_t kind = RM_OP_KIND(q.op);
+                const double c1 = std::fabs((double)q.p[0]) + std::fabs((double)q.p[1]) + std::fabs((double)q.p[2]);
+                double R, rin;
+                if (kind == RM_KIND_SPHERE) {
+                    R = std::fmax((double)q.p[3], 0.0);
+                    rin = (double)q.p[3];
+                } else if (kind == RM_KIND_BOX) {
+                    const double h[3] = {q.p[3], q.p[4], q.p[5]};
+                    R = std::sqrt(std::pow(std::fmax(h[0], 0.0), 2) + std::pow(std::fmax(h[1], 0.0), 2) + std::pow(std::fmax(h[2], 0.0), 2));
+                    rin = std::fmin(h[0], std::fmin(h[1], h[2]));
+                    if (!(h[0] >= 0.0 && h[1] >= 0.0 && h[2] >= 0.0)) rin = -(std::fabs(h[0]) + std::fabs(h[1]) + std::fabs(h[2]));  // (also takes a NaN)
+                } else {  // cylinder: radius, half height
+                    const double r = q.p[3], hh = q.p[4];
+                    R = std::sqrt(std::pow(std::fmax(r, 0.0), 2) + std::pow(std::fmax(hh, 0.0), 2));
+                    rin = std::fmin(r, hh);
+                    if (!(r >= 0.0 && hh >= 0.0)) rin = -(std::fabs(r) + std::fabs(hh));
+                }
+                g.p[0] = q.p[0]; g.p[1] = q.p[1]; g.p[2] = q.p[2];
+                // a parameter that is not a finite number: the formulas above say nothing (max(NaN, 0) = 0 makes a box with a NaN
+                // extent an infinite slab, not a small box): no bound at all
+                bool finite = std::isfinite(c1);
+                for (int k = 3; k < (kind == RM_KIND_SPHERE ? 4 : kind == RM_KIND_BOX ? 6 : 5); k++) finite = finite && std::isfinite((double)q.p[k]);
+                if (!finite) { R = 1.0 / 0.0; rin = -1.0 / 0.0; }
+                const double Rp = (R + 2.0e-6 * (c1 + R)) * (1.0 + 1.0e-6);
+                g.p[3] = std::nextafterf((float)((double)std::nextafterf((float)Rp, INFINITY) * 1.000005), INFINITY);  // a NaN stays one: never far
+                const double rd = rin - 2.0e-6 * (c1 + std::fabs(rin)) - 1.0e-30;
+                g.p[4] = std::nextafterf((float)rd, -INFINITY);
+                if (!finite) { g.p[0] = g.p[1] = g.p[2] = 0.0f; g.p[3] = inf; g.p[4] = -inf; }
+                if (u.k_rec >= 0) {
+                    const float k = d.rec[(size_t)u.k_rec].p[0];
+                    g.p[5] = k > 0.0f ? k : 0.0f;
+                    if (g.p[5] > d.unit_kmax) d.unit_kmax = g.p[5];
+                }
+            }
+            d.units.push_back(g);
         }
-    }
-    if (!d.prunable && !d.has_xforms && rm_has_blend(d.rec)) {  // the local rule, see RmDecoded::blend_prunable
-        d.blend_prunable = true;
-        auto k_of = [&](int leaf) {
-            const RmLeafUse u = rm_leaf_use(d.rec, (size_t)leaf);
-            const double k = u.k_rec >= 0 ? (double)d.rec[(size_t)u.k_rec].p[0] : 0.0;
-            return k > 0.0 ? k : 0.0;
-        };
-        for (const std::pair<int, int>& pr : rm_blend_pairs(d.rec))
-            d.groups.push_back(pair_record(d.rec[(size_t)pr.first], d.rec[(size_t)pr.second], std::fmax(k_of(pr.first), k_of(pr.second))));
+        if (d.unit_mode == RM_UNITS_LATTICE) {  // how to step over a right operand, see RmDecoded::is_tree
+            for (size_t ui = 0; ui < us.size(); ui++) {
+                const size_t i = (size_t)us[ui].first;
+                uint32_t info = 0u;
+                if (RM_OP_MODE(d.rec[i].op) == RM_MODE_PUSH && (d.rec[i].op & RM_OP_SPILL)) {
+                    int depth = 1;  // counted from the accumulator that spilled
+                    uint32_t leaves = 0u;
+                    size_t j = i;
+                    bool plain = true;  // only leaves and operators inside (no transform, nothing unbounded)
+                    for (; j < d.rec.size(); j++) {
+                        const uint32_t kj = RM_OP_KIND(d.rec[j].op), mj = RM_OP_MODE(d.rec[j].op);
+                        if (kj == RM_KIND_POP) depth--;
+                        else if (rm_bounded_leaf(kj)) { leaves++; if (mj == RM_MODE_PUSH) depth++; }
+                        else plain = false;
+                        if (depth == 1) break;
+                    }
+                    if (j < d.rec.size() && plain && leaves <= 64u && j - i + 1u < 65536u &&
+                        (RM_OP_MODE(d.rec[j].op) == RM_MODE_UNION || RM_OP_MODE(d.rec[j].op) == RM_MODE_SUB))
+                        info = (uint32_t)(j - i + 1u) | (leaves << 16) | (1u << 24);
+                }
+                std::memcpy(&d.units[ui].p[4], &info, 4);
+            }
+        }
     }
     if (!d.rec.empty()) {
         const RmRecord& r0 = d.rec[0];
         d.is_chain = (RM_OP_KIND(r0.op) == RM_KIND_SPHERE || RM_OP_KIND(r0.op) == RM_KIND_BOX) && RM_OP_MODE(r0.op) == RM_MODE_PUSH &&
                      (r0.op & RM_OP_SPILL) == 0u;
-        for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) != 0u;
+        for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) >= 1u && RM_OP_FASTCLASS(d.rec[i].op) <= 4u;
+        d.is_tree = true;
+        for (const RmRecord& r : d.rec) d.is_tree = d.is_tree && RM_OP_FASTCLASS(r.op) != 0u;
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     // (a Plane the tables would have to clear: they cannot; an Intersection: they ask a ray to clear BOTH operands where

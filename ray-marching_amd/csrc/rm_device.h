@@ -21,7 +21,7 @@
 // The arithmetic performed on each value is exactly the reference's, in the same order;
 // only the bookkeeping (where a value lives) changes.
 struct RmRecord {
-    uint32_t op;  // kind | mode<<3 | spill<<6 | fast class<<16
+    uint32_t op;  // kind | mode<<3 | spill<<6 | nocull<<7 | (unit + 1)<<8 | fast class<<16
     float p[7];   // sphere: cx cy cz r [r * 1.000005, for specialised kernels]   box: cx cy cz rx ry rz   cylinder: cx cy cz r half_h
                   // plane: nx ny nz h    POP+SMOOTH: k            p[6] (primitives): slot in the miss-test tables
 };
@@ -42,11 +42,20 @@ enum : uint32_t { RM_OP_SPILL = 1u << 6 };
 // registers a hit (wgsl:97) only within the margin of a leaf of the LEFT operand, however close the ray comes to b
 // (rm_decode.h, rm_kernel_v5.h cull_build_v5)
 enum : uint32_t { RM_OP_NOCULL = 1u << 7 };
-// Interpreter fast class (bits 16-18; generated code and the v1 kernel ignore it): the four record shapes that make up a
-// left-deep chain -- a sphere / box leaf fused with the Union / Subtraction that consumes it, on a live accumulator, no
-// stack traffic -- are dispatched with two decisions instead of the generic kind / spill / mode ladder (rm_interp.h).
-//   0 generic   1 sphere + union   2 box + union   3 sphere + subtraction   4 box + subtraction
-#define RM_OP_FASTCLASS(op) (((op) >> 16) & 7u)
+// Interpreter fast class (bits 16-19; generated code and the v1 kernel ignore it).  The eight record shapes a reference-only
+// program (spheres, boxes, Union, Subtraction) decodes into are dispatched with two or three decisions instead of the generic
+// kind / spill / mode ladder (rm_interp.h):
+//   1 sphere + union   2 box + union   3 sphere + subtraction   4 box + subtraction      leaf fused with its operator, on the accumulator
+//   5 sphere pushed    6 box pushed                                                      (the accumulator spills first if RM_OP_SPILL)
+//   7 union            8 subtraction                                                     of the popped value and the accumulator
+//   0 generic (extension node types)
+// A left-deep chain is classes 5 / 6 for record 0 and 1..4 behind it (RmDecoded::is_chain); a program whose records all have a
+// class is a TREE (RmDecoded::is_tree).
+#define RM_OP_FASTCLASS(op) (((op) >> 16) & 15u)
+// Unit of wave-level culling the record belongs to, plus one (bits 8-15; 0: none, the record is always executed): a lattice
+// program's bounded leaves, every record of a blending chain's units (rm_units.h).  The interpreter's general loop skips a
+// record whose unit's bit is clear in the wave's mask; generated code has the bits as constants and ignores the field.
+#define RM_OP_UNIT(op) (((op) >> 8) & 0xFFu)
 
 // reference opcodes (csg/builder.rs:1-24)
 enum : uint32_t { RM_CMD_SPHERE = 0, RM_CMD_BOX = 1, RM_CMD_UNION = 100, RM_CMD_SUBTRACTION = 101 };
@@ -62,18 +71,24 @@ enum : uint32_t { RM_CMD_TRANSLATION_PUSH = 200, RM_CMD_TRANSLATION_POP = 201, R
 // one u32 parameter (the index, not f32 bits).  Semantics: oracle/rm_oracle.c map_scene_impl.
 enum : uint32_t { RM_CMD_MATERIAL = 300, RM_MAX_MATERIALS = 256 };
 
+// Units of wave-level culling (rm_units.h, rm_kernel_v5.h): kind of a unit record (its p[6], as an integer), and what
+// RmLaunch::unit_mode says about the program
+enum : uint32_t { RM_UNIT_START = 0, RM_UNIT_UM = 1, RM_UNIT_SUB = 2, RM_UNIT_INTER = 3, RM_UNIT_OPAQUE = 4, RM_UNIT_LEAF = 5 };
+enum : uint32_t { RM_UNITS_NONE = 0, RM_UNITS_LATTICE = 1, RM_UNITS_BLEND = 2 };
+
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
     uint32_t n_rec;            // == cmd_count of the reference program
-    uint32_t n_grp;            // group records that follow the n_rec program records in `prog` (far-primitive pruning: one
-                               // bounding sphere per pair of consecutive sphere / box leaves, RmDecoded::groups); staged in
-                               // LDS with the program
+    uint32_t n_grp;            // unit records that follow the n_rec program records in `prog` (wave-level culling: one bounded
+                               // stand-in per unit, RmDecoded::units); staged in LDS with the program
+    uint32_t unit_mode;        // RM_UNITS_* (rm_units.h): 0 none, 1 lattice program (threshold rule), 2 blending chain
+    float unit_kmax;           // the largest blend radius of a unit (the chain of blends never falls further below its smallest leaf)
     uint32_t spill_depth;      // LDS slots per lane this program needs: value stack, then 3 per transform level
     uint32_t value_spill_depth; // the value-stack part of spill_depth (saved positions start at this slot)
     const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:
                                // programs with transforms (their miss tests use these instead of the parameters)
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
-    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 3: ... with far pairs skipped (map_scene_chain_pruned); bit 5: miss test on lower bounds (RmDecoded::bound_walk)
+    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 4: tree program (map_scene_tree); bit 3: ... with far pairs skipped (map_scene_chain_pruned); bit 5: miss test on lower bounds (RmDecoded::bound_walk); bits 8-14: diagnostics (RM_PRE_NEED_MAX)
     uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program
     float smooth_slack;        // sum of k/4 over SmoothUnion operators: how far they can lower the tree value
     float scene_scale;         // 1 + max |centre|_1 + |size|_1 over the primitives (RmDecoded::scene_scale)

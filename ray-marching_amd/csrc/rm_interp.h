@@ -111,18 +111,32 @@ RM_DEV void xf_rotate_conj(float w, float ax, float ay, float az, float& x, floa
 // One decoded command applied to the R positions of a lane.
 // EXT = false compiles the reference's four node types only (the lean, measured path); EXT = true
 // adds the extension node types.  Which one runs is decided per program on the host.
-template <int R, bool FAST, bool EXT = false>
+// need / unit_mode: the wave's unit mask (rm_kernel_v5.h "Wave-level culling"); a record whose unit's bit is clear is skipped --
+// in a lattice program its leaf is +inf (a pushed leaf still pushes), in a blending chain nothing happens at all (the unit's
+// records leave the stack as they found it; the leaf that starts the chain leaves +inf).
+template <int R, bool FAST, bool EXT = false, bool MASKED = false>
 RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float (&qy)[R], float (&qz)[R], float (&acc)[R],
-                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u) {
+                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u, unsigned long long need = ~0ull,
+                         uint32_t unit_mode = 0u) {
     // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
     op = __builtin_amdgcn_readfirstlane(op);
+    const uint32_t un = MASKED ? RM_OP_UNIT(op) : 0u;
+    const bool far = MASKED && un != 0u && ((need >> (un - 1u)) & 1ull) == 0ull;  // wave-uniform
+    if (far && unit_mode == RM_UNITS_BLEND) {
+        if (RM_OP_KIND(op) != RM_KIND_POP && RM_OP_MODE(op) == RM_MODE_PUSH && (op & RM_OP_SPILL) == 0u) {  // the chain's first leaf
+#pragma unroll
+            for (int k = 0; k < R; k++) acc[k] = __uint_as_float(0x7F800000u);
+        }
+        return;
+    }
     // The records of a left-deep chain (RM_OP_FASTCLASS): leaf, then min / max(., -leaf) into the accumulator; no stack slot
     // is read or written, nothing merges with the generic path below (whose value copies at the joins of its kind / spill /
     // mode ladder cost ~6 v_mov, ~8 branches and ~20 scalar instructions per record).
     const uint32_t cls = RM_OP_FASTCLASS(op);
-    if (cls != 0u) {
+    if (cls != 0u && cls <= 4u) {
+        if (far) return;  // min(acc, +inf), max(acc, -inf)
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const float b = (cls & 1u) ? sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny) : sdf_box_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
@@ -158,7 +172,10 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
             a[k] = spill[(sp * R + k) * 64u];
         }
     } else {
-        if (kind == RM_KIND_SPHERE) {
+        if (far) {  // a far leaf of a lattice program
+#pragma unroll
+            for (int k = 0; k < R; k++) b[k] = __uint_as_float(0x7F800000u);
+        } else if (kind == RM_KIND_SPHERE) {
 #pragma unroll
             for (int k = 0; k < R; k++) b[k] = sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
         } else if (!EXT || kind == RM_KIND_BOX) {
@@ -208,10 +225,10 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
 // map_scene (wgsl:187-203) for R positions per lane.  Commands are fetched one ahead of their
 // use (two buffers, loop unrolled by two) so that the fetch latency hides behind the VALU work
 // of the previous command.
-template <int R, bool FAST, class Prog, bool EXT = false>
+template <int R, bool FAST, class Prog, bool EXT = false, bool MASKED = false>
 RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx_in)[R],
                             const float (&qy_in)[R], const float (&qz_in)[R], float (&out)[R], SqrtGuard& tiny,
-                            uint32_t xf_base = 0u) {
+                            uint32_t xf_base = 0u, unsigned long long need = ~0ull, uint32_t unit_mode = 0u) {
     float qx[R], qy[R], qz[R];  // transform commands (EXT) change the evaluation position
 #pragma unroll
     for (int k = 0; k < R; k++) { qx[k] = qx_in[k]; qy[k] = qy_in[k]; qz[k] = qz_in[k]; }
@@ -229,7 +246,7 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
         uint32_t op0;
         float p0[7];
         prog.load(c, op0, p0);
-        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+        exec_command<R, FAST, EXT, MASKED>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
     }
 #else
     uint32_t op0, op1;
@@ -237,10 +254,10 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     prog.load(0u, op0, p0);
     for (;;) {
         prog.load(c + 1u < n_rec ? c + 1u : c, op1, p1);
-        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+        exec_command<R, FAST, EXT, MASKED>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
         if (++c == n_rec) break;
         prog.load(c + 1u < n_rec ? c + 1u : c, op0, p0);
-        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base);
+        exec_command<R, FAST, EXT, MASKED>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
         if (++c == n_rec) break;
     }
 #endif
@@ -251,70 +268,110 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
 // map_scene for a CHAIN program (RmDecoded::is_chain): record 0 pushes a sphere / box, every later record is a sphere / box
 // fused with the Union / Subtraction that consumes it (RM_OP_FASTCLASS != 0) -- what the reference's editor produces for
 // "a op b op c ..." and what both metric scenes are.  No value stack, no opcode ladder: two decisions per record (which
-// leaf, which operator), the records fetched one ahead of their use.  Same leaf functions, same operators, same order as
-// exec_command: the same bits.
+// leaf, which operator).  Same leaf functions, same operators, same order as exec_command: the same bits.
+// masked: `need` is the wave's unit mask (rm_kernel_v5.h "Wave-level culling"; in a chain of at most 64 records unit u IS record
+// u): a record whose bit is clear is not even fetched -- its leaf is +inf, which min and max(., -.) ignore -- and the loop
+// walks the set bits.  Records are fetched one ahead of their use either way.
 template <bool FAST, class Prog>
-RM_DEV float map_scene_chain(const Prog& prog, uint32_t n_rec, float x, float y, float z, SqrtGuard& tiny) {
+RM_DEV float map_scene_chain(const Prog& prog, uint32_t n_rec, float x, float y, float z, unsigned long long need, bool masked, SqrtGuard& tiny) {
     uint32_t opa, opb;
     float pa[7], pb[7];
-    prog.load(0u, opa, pa);
-    prog.load(n_rec > 1u ? 1u : 0u, opb, pb);
-    opa = __builtin_amdgcn_readfirstlane(opa);
-    float acc = RM_OP_KIND(opa) == RM_KIND_SPHERE ? sdf_sphere_t<FAST>(x, y, z, pa, tiny) : sdf_box_t<FAST>(x, y, z, pa, tiny);
-    auto apply = [&](uint32_t op, const float (&p)[7]) {
-        const uint32_t cls = RM_OP_FASTCLASS(__builtin_amdgcn_readfirstlane(op));
+    float acc = __uint_as_float(0x7F800000u);
+    auto apply = [&](uint32_t c, uint32_t op, const float (&p)[7]) {
+        op = __builtin_amdgcn_readfirstlane(op);
+        if (c == 0u) {  // record 0 pushes its value
+            acc = RM_OP_KIND(op) == RM_KIND_SPHERE ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);
+            return;
+        }
+        const uint32_t cls = RM_OP_FASTCLASS(op);
         const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);
         acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
     };
+    if (masked) {
+        unsigned long long m = need;  // (bits at and above n_rec are clear)
+        if (m == 0ull) return acc;
+        uint32_t ca = (uint32_t)__builtin_ctzll(m), cb = 0u;
+        m &= m - 1ull;
+        prog.load(ca, opa, pa);
+        for (;;) {  // record ca waits in (opa, pa)
+            const bool more = m != 0ull;
+            if (more) { cb = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; prog.load(cb, opb, pb); }
+            apply(ca, opa, pa);
+            if (!more) break;
+            const bool more2 = m != 0ull;
+            if (more2) { ca = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; prog.load(ca, opa, pa); }
+            apply(cb, opb, pb);
+            if (!more2) break;
+        }
+        return acc;
+    }
+    prog.load(0u, opa, pa);
+    prog.load(n_rec > 1u ? 1u : 0u, opb, pb);
+    apply(0u, opa, pa);
     for (uint32_t c = 1u; c < n_rec; c += 2u) {  // record c waits in (opb, pb)
         prog.load(c + 1u < n_rec ? c + 1u : c, opa, pa);
-        apply(opb, pb);
+        apply(c, opb, pb);
         if (c + 1u >= n_rec) break;
         prog.load(c + 2u < n_rec ? c + 2u : c + 1u, opb, pb);
-        apply(opa, pa);
+        apply(c + 1u, opa, pa);
     }
     return acc;
 }
 
-// The chain loop with far-primitive pruning (rm_kernel_v5.h "Pruning": exact -- a leaf farther than thr from every live lane
-// is replaced by +inf, which min / max(., -.) ignore).  The decoder pairs consecutive leaves (RmDecoded::groups); in a chain
-// pair g is records 2g and 2g + 1 and its bounding sphere is record n_rec + g.  One test per pair (the bound may use fused
-// multiply-adds: it is not a value of the arithmetic contract), members of a far pair are not even fetched; an odd last
-// record has no pair and is always evaluated.  Members of a near pair get no test of their own: measured (round 2, metric
-// frame) 1.09 ms without, 1.19 ms with the per-leaf tests the generated code runs.
-template <bool FAST, class Prog>
-RM_DEV float map_scene_chain_pruned(const Prog& prog, uint32_t n_rec, float x, float y, float z, float thr, unsigned long long live,
-                                    SqrtGuard& tiny) {
-    const float thrk = thr * 1.000005f;
-    const uint32_t n_pair = n_rec >> 1u;
-    float acc = __uint_as_float(0x7F800000u);
-    auto any_near = [&](bool far) -> bool { return (__builtin_amdgcn_ballot_w64(!far) & live) != 0ull; };
-    auto apply = [&](uint32_t op, const float (&p)[7]) {
-        const uint32_t cls = RM_OP_FASTCLASS(__builtin_amdgcn_readfirstlane(op));
-        const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);
-        acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
+// map_scene for a TREE program (RmDecoded::is_tree): spheres and boxes under Union / Subtraction in any arrangement -- what the
+// reference's node-graph editor can produce at all (csg/mod.rs:28-45) -- decoded into the eight record shapes of
+// RM_OP_FASTCLASS.  One dispatch per record, the popped operands in the wave's LDS spill column; same leaf functions, same
+// operators, same order as exec_command: the same bits.
+// MASKED: `need` is the wave's unit mask (rm_kernel_v5.h "Wave-level culling").  A leaf whose bit is clear is +inf: fused, its
+// record is a no-op; pushed, it pushes +inf -- unless it starts the right operand of a Union / Subtraction none of whose
+// leaves is needed: the whole operand is +inf then, min(a, +inf) and max(a, -inf) are a, and the loop steps over all its
+// records at once (`span`: the unit table's row 4, RmDecoded::is_tree).
+template <bool FAST, bool MASKED, class Prog>
+RM_DEV float map_scene_tree(const Prog& prog, uint32_t n_rec, float* spill, float x, float y, float z, unsigned long long need,
+                            const uint32_t* span, SqrtGuard& tiny) {
+    const float inf = __uint_as_float(0x7F800000u);
+    float acc = inf;
+    uint32_t sp = 0u, c = 0u;
+    uint32_t op0, op1;
+    float p0[7], p1[7];
+    // the record at c waits in (opc, pc); the next one is fetched into (opn, pn) before c is executed.  true: the program is done
+    auto step = [&](uint32_t& opc, float (&pc)[7], uint32_t& opn, float (&pn)[7]) -> bool {
+        for (;;) {
+            const uint32_t op = __builtin_amdgcn_readfirstlane(opc);
+            const uint32_t cls = RM_OP_FASTCLASS(op), un = RM_OP_UNIT(op);
+            const bool far = MASKED && un != 0u && ((need >> (un - 1u)) & 1ull) == 0ull;  // wave-uniform
+            if (MASKED && far && (cls == 5u || cls == 6u) && (op & RM_OP_SPILL)) {
+                const uint32_t info = span[un - 1u];  // wave-uniform address
+                const uint32_t leaves = (info >> 16) & 0xFFu;
+                const unsigned long long inside = (leaves >= 64u ? ~0ull : ((1ull << leaves) - 1ull)) << (un - 1u);
+                if ((info >> 24) != 0u && (need & inside) == 0ull) {  // the whole right operand is +inf
+                    c += info & 0xFFFFu;
+                    if (c >= n_rec) return true;
+                    prog.load(c, opc, pc);
+                    continue;
+                }
+            }
+            prog.load(c + 1u < n_rec ? c + 1u : c, opn, pn);
+            if (cls <= 4u) {  // (class 0 does not occur in a tree program)
+                if (!far) {
+                    const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny);
+                    acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
+                }
+            } else if (cls <= 6u) {
+                if (op & RM_OP_SPILL) { spill[sp * 64u] = acc; ++sp; }
+                acc = far ? inf : (cls == 5u ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny));
+            } else {
+                --sp;
+                const float a = spill[sp * 64u];
+                acc = cls == 7u ? vmin(a, acc) : vmax_negb(a, acc);
+            }
+            return ++c == n_rec;
+        }
     };
-    auto first = [&](uint32_t op, const float (&p)[7]) {  // record 0 pushes its value
-        acc = RM_OP_KIND(__builtin_amdgcn_readfirstlane(op)) == RM_KIND_SPHERE ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);
-    };
-    uint32_t op0, op1, gop;
-    float p0[7], p1[7], g[7];
-    for (uint32_t k = 0u; k < n_pair; k++) {
-        prog.load(n_rec + k, gop, g);
-        const float dx = x - g[0], dy = y - g[1], dz = z - g[2];
-        const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-        const float t = thrk + g[3];  // g[3] = R' * 1.000005 (decoder)
-        if (!any_near(a > t * t)) continue;
-        prog.load(2u * k, op0, p0);
-        prog.load(2u * k + 1u, op1, p1);
-        if (k == 0u) first(op0, p0);
-        else apply(op0, p0);
-        apply(op1, p1);
-    }
-    if (n_rec & 1u) {
-        prog.load(n_rec - 1u, op0, p0);
-        if (n_rec == 1u) first(op0, p0);
-        else apply(op0, p0);
+    prog.load(0u, op0, p0);
+    for (;;) {
+        if (step(op0, p0, op1, p1)) break;
+        if (step(op1, p1, op0, p0)) break;
     }
     return acc;
 }

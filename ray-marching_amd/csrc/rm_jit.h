@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <sys/stat.h>
 #include <unistd.h>
 #include <map>
 #include <memory>
@@ -35,7 +36,7 @@
 #include <vector>
 
 #include "rm_device.h"
-#include "rm_groups.h"
+#include "rm_units.h"
 
 namespace rmjit {
 
@@ -121,988 +122,273 @@ inline std::string structure_key(const std::vector<RmRecord>& rec) {
 
 inline bool can_specialise(const std::vector<RmRecord>& rec) { return !rec.empty() && rec.size() <= kMaxRecords; }
 
-// Straight-line map_scene for `rec`, mirroring exec_command (rm_interp.h) record by record
-// with the value stack resolved at generation time: the accumulator and every spilled value become
-// named values.  With `prune`, sphere and box leaves are wrapped in the wave-uniform far test of
-// rm_kernel_v5.h ("Pruning").  Returns false if the records do not form a valid program (cannot
-// happen for the output of rm_decode_program).
 // A/B knobs of the generated code (environment, read when a structure is generated; defaults are the measured best)
 inline int jit_knob(const char* name, int dflt) {
     const char* v = std::getenv(name);
     return v ? std::atoi(v) : dflt;
 }
 
-inline bool generate_map_scene(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
-    // diagnostics (tools/wave_stats.py): 1 counts evaluated leaves, 2 leaf tests executed (leaves of near groups), 3 near groups,
-    // 4 (group, lane) pairs that are near
-    const int count_mode = prune ? jit_knob("RM_JIT_PRUNE_STATS", 0) : 0;
-    const bool count = count_mode == 1;
-    std::string s;
-    char line[512];
-    s += "namespace rmk {\n";
-    s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
-    if (prune) {
-        s += "    const float thrk = thr * 1.000005f;\n";          // sphere test: ((thr + r) k)^2
-        s += "    const float thr2k = (thr * thr) * 1.00001f;\n";  // box test
-        s += "    const float inf = __uint_as_float(0x7F800000u);\n";
-    }
-    // A scheduling barrier after every 4 leaves: left alone the compiler hoists the parameter loads of the whole
+// prune: 0 every leaf is evaluated, 1 a lattice program (min / max over bounded leaves) whose leaves sit behind a bit of the
+// mask wave-level culling computes (threshold rule), 2 a program that blends whose top-level chain's units do (rm_units.h,
+// rm_kernel_v5.h "Wave-level culling")
+enum : int { PRUNE_NONE = 0, PRUNE_LATTICE = 1, PRUNE_BLEND = 2 };
+
+// Straight-line code for `rec`, mirroring exec_command (rm_interp.h) record by record with the value stack resolved at
+// generation time: the accumulator and every spilled value become named values, no opcode decode, no loop; parameters are
+// read from the LDS copy of the program at constant offsets.  One generator for both functions of a translation unit:
+//   T = 1   map_scene_spec<FAST>(lp, qx, qy, qz, need, live, tiny, n_eval): the value at one position per lane
+//   T = 4   map_scene_taps<FAST>(lp, cx, cy, cz, need, live, tiny, f): the four normal taps of a hit at c (wgsl:135-144) in one
+//           pass -- every record applied to the four positions c + k_t eps with the same leaf functions and operators, so
+//           each f[t] goes through the operations a separate evaluation would; the compiler sees that the twelve
+//           coordinates take only six different values, and one loop trip replaces four
+// With pruning, a UNIT (rm_units.h) is code behind one bit of `need`, which the caller computed for the whole wave:
+//   lattice programs   every bounded leaf; skipped, it is +inf where it is pushed or intersected ("acc = min(acc, +inf)" and
+//                      "acc = max(acc, -inf)" leave the accumulator alone)
+//   blending chains    every step of the top-level chain -- the leaf that starts it (skipped: +inf, which the first unit
+//                      that is needed, a restart, turns into its own leaf's value: smin(+inf, v) = v), a leaf with its Union /
+//                      SmoothUnion / Subtraction / Intersection (skipped: the accumulator stays), an opaque stretch of records
+// Returns false if the records do not form a valid program (cannot happen for the output of rm_decode_program) or the
+// program has no units of the kind asked for.
+inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int T, std::string* out) {
+    const int count_mode = (prune && T == 1) ? jit_knob("RM_JIT_PRUNE_STATS", 0) : 0;  // 1: leaves evaluated (tools/wave_stats.py)
+    const char* counted = count_mode == 1 ? " n_eval += 1u;" : "";
+    // A scheduling barrier after every few leaves: left alone the compiler hoists the parameter loads of the whole
     // program to the top of the straight-line code (88 VGPRs for 16 leaves, 120-139 for 32: 3 waves per SIMD);
     // with the barriers 61-62 VGPRs whatever the length.  64-node scene at 4K 636 -> 682 Mpx/s, metric frame +2 %.
-    // (RM_JIT_SCHED_BARRIER=N overrides, 0 disables.)
-    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
-    int leaves = 0;
-    // Grouped far tests: consecutive sphere / box leaves pair up (RmDecoded::groups: pair g = pruned leaves 2g, 2g + 1;
-    // its bounding sphere is record n_rec + g of the LDS copy); one test clears both members.
-    int n_pruned_total = 0, n_pruned = 0;
-    // Members of a near pair: a box keeps a far test of its own behind the pair's (one compare on a value it computes
-    // anyway, saves the square root and the inside term), a sphere does not (its test is three more vector instructions
-    // and a branch to save five).  Measured (RM_JIT_LEAF_TESTS: 1 both / 0 neither / 2 boxes = default / 3 spheres), march
-    // kernel of the metric frame 0.780 / 0.780 / 0.761 / 0.784 ms, G64 at 4K 7.38 / 7.46 / 7.31 / 7.47 ms.
-    const int leaf_tests = jit_knob("RM_JIT_LEAF_TESTS", 2);
-    const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0;  // A/B: the local test of subtracted leaves (below)
-    for (const RmRecord& r : rec) n_pruned_total += prune && (RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX);
-    std::vector<int> stack;  // value numbers; back() is the accumulator
-    std::vector<int> pos;    // position numbers of the open transform scopes; back() is the current one (0 = qx, qy, qz)
-    int nv = 0, np = 0;
-    s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
-    pos.push_back(0);
-    // all group tests up front: their LDS reads go out together instead of one stalling in front of every pair
-    for (int g = 0; 2 * g + 1 < n_pruned_total; g++) {
-        const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u;
-        std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, x0, y0, z0, thrk);\n", g, goff);
-        s += line;
-        if (count_mode == 3) { std::snprintf(line, sizeof line, "    if (g%d) n_eval += 1u;\n", g); s += line; }
-        if (count_mode == 4) {  // lanes for which the group is near (what a perfectly coherent wave would pay for)
-            std::snprintf(line, sizeof line, "    n_eval += spec_group_near_lanes(live, lp + %u, x0, y0, z0, thrk);\n", goff);
-            s += line;
-        }
-    }
-    for (size_t i = 0; i < rec.size(); i++) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u;  // first parameter of record i, in dwords (records are staged rotated: lds_load4)
-        if (kind == RM_KIND_XFORM) {  // space transformation: a new position value (push) or back to the enclosing one (pop)
-            const int c = pos.back();
-            if ((mode & 1u) == 0u) {
-                const int n = ++np;
-                if (mode == RM_XF_T_PUSH)
-                    std::snprintf(line, sizeof line, "    const float x%d = x%d - lp[%u], y%d = y%d - lp[%u], z%d = z%d - lp[%u];\n",
-                                  n, c, off, n, c, off + 1u, n, c, off + 2u);
-                else if (mode == RM_XF_R_PUSH)
-                    std::snprintf(line, sizeof line, "    float x%d = x%d, y%d = y%d, z%d = z%d; xf_rotate_conj(lp[%u], lp[%u], lp[%u], lp[%u], x%d, y%d, z%d);\n",
-                                  n, c, n, c, n, c, off, off + 1u, off + 2u, off + 3u, n, n, n);
-                else
-                    std::snprintf(line, sizeof line, "    const float x%d = x%d / lp[%u], y%d = y%d / lp[%u], z%d = z%d / lp[%u];\n",
-                                  n, c, off, n, c, off, n, c, off);
-                s += line;
-                pos.push_back(n);
-            } else {
-                if (pos.size() < 2 || stack.empty()) return false;
-                pos.pop_back();
-                if (mode == RM_XF_S_POP) {
-                    const int a = stack.back(); stack.pop_back();
-                    const int w = nv++;
-                    std::snprintf(line, sizeof line, "    const float v%d = v%d * lp[%u];\n", w, a, off);
-                    s += line;
-                    stack.push_back(w);
-                }
-            }
-            continue;
-        }
-        char P[64];  // "xN, yN, zN": the position this record's leaf is evaluated at
-        std::snprintf(P, sizeof P, "x%d, y%d, z%d", pos.back(), pos.back(), pos.back());
-        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
-        if (kind == RM_KIND_POP) {
-            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            const int b = stack.back(); stack.pop_back();
-            const int a = stack.back(); stack.pop_back();
-            const int w = nv++;
-            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d, live);\n", w, off, a, b);
-            else if (op) std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, v%d);\n", w, op, a, b);
-            else return false;
-            s += line;
-            stack.push_back(w);
-            continue;
-        }
-        if (mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;  // the decoder never fuses an operator with a parameter
-        int a = -1;
-        if (mode != RM_MODE_PUSH) {
-            if (stack.empty()) return false;
-            a = stack.back(); stack.pop_back();
-        }
-        const int w = nv++;  // the record's result: the leaf (PUSH) or op(acc, leaf)
-        const bool pruned = prune && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX);
-        if (pruned) {
-            // result if the leaf is far for every live lane: +inf (PUSH), acc (UNION: min(acc, +inf); SUB: max(acc, -inf));
-            // Intersection max(acc, +inf) = +inf
-            if (mode == RM_MODE_PUSH || mode == RM_MODE_INTER) std::snprintf(line, sizeof line, "    float v%d = inf;\n", w);
-            else std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
-            s += line;
-            char leaf[128];
-            const int ordinal = n_pruned++, grp = ordinal / 2;
-            if ((ordinal | 1) < n_pruned_total) {  // this leaf has a partner
-                std::snprintf(line, sizeof line, "    if (g%d)\n", grp);
-                s += line;
-            }
-            const char* tested = count_mode == 2 ? "n_eval += 1u; " : "";
-            const bool paired = (ordinal | 1) < n_pruned_total;
-            bool own_test = !paired || leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
-            // A SUBTRACTED leaf changes max(acc, -v) only where -v > acc: at a position outside it (v > 0) with acc >= 0 -- a ray
-            // that is not inside anything -- never.  That is a test on values at hand (the squared distance, the accumulator),
-            // sharper than the threshold test it replaces wherever acc >= 0, and exact without any Lipschitz argument.
-            const bool local_sub = mode == RM_MODE_SUB && sub_tests;
-            if (local_sub) {
-                own_test = true;
-                if (kind == RM_KIND_SPHERE) {
-                    std::snprintf(line, sizeof line, "    { %sconst float a = spec_sphere_a(lp + %u, %s);\n      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) ", tested, off, P, off, a);
-                    std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
-                } else {
-                    std::snprintf(line, sizeof line, "    { %sconst SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_sub_box_near(live, b.a, v%d)) ", tested, off, P, a);
-                    std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
-                }
-            } else if (!own_test) {  // a member of a near pair is evaluated without a test of its own
-                std::snprintf(leaf, sizeof leaf, "%s<FAST>(lp + %u, %s, tiny)", kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, P);
-                std::snprintf(line, sizeof line, "    %s", tested);
-            } else if (kind == RM_KIND_SPHERE) {
-                std::snprintf(line, sizeof line, "    { %sconst float a = spec_sphere_a(lp + %u, %s);\n      if (spec_any_near(live, spec_sphere_far(lp + %u, a, thrk))) ", tested, off, P, off);
-                std::snprintf(leaf, sizeof leaf, "spec_sphere_v<FAST>(lp + %u, a, tiny)", off);
-            } else {
-                std::snprintf(line, sizeof line, "    { %sconst SpecBox b = spec_box_a(lp + %u, %s);\n      if (spec_any_near(live, b.a > thr2k)) ", tested, off, P);
-                std::snprintf(leaf, sizeof leaf, "spec_box_v<FAST>(b, tiny)");
-            }
-            s += line;
-            const char* close = own_test ? " }" : "";
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "{ v%d = %s; %s}%s\n", w, leaf, count ? "n_eval += 1u; " : "", close);
-            else std::snprintf(line, sizeof line, "{ v%d = %s(v%d, %s); %s}%s\n", w, op, a, leaf, count ? "n_eval += 1u; " : "", close);
-            s += line;
-        } else {
-            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
-                           : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
-            if (!fn) return false;
-            char leaf[128];
-            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, %s)", fn, off, P);
-            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, %s, tiny)", fn, off, P);
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d = %s;\n", w, leaf);
-            else std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, %s);\n", w, op, a, leaf);
-            s += line;
-        }
-        stack.push_back(w);
-        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
-    }
-    if (stack.empty()) return false;
-    std::snprintf(line, sizeof line, "    return v%d;\n}\n}  // namespace rmk\n", stack.back());
-    s += line;
-    *out = std::move(s);
-    return true;
-}
+    const int sched_every = T == 1 ? (std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4)
+                                   : (std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2);
+    const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0 && T == 1;  // the local test of subtracted leaves (below)
+    const bool fence = T == 4 && jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;    // see guard_fence (rm_kernel_v5.h)
+    std::vector<RmUnit> units;
+    if (prune == PRUNE_LATTICE && !rm_lattice_units(rec, &units)) return false;
+    if (prune == PRUNE_BLEND && !rm_blend_units(rec, &units)) return false;
+    std::vector<int> unit_at(rec.size(), -1);
+    for (size_t u = 0; u < units.size(); u++) unit_at[(size_t)units[u].first] = (int)u;
 
-// The four normal taps of a hit (wgsl:135-144) in one pass over the program: every record is applied to the four
-// positions c + k_t eps with the leaf functions and operators map_scene_spec uses, so each f[t] goes through the same
-// operations as a separate evaluation would -- but the compiler sees that the twelve coordinates take only six
-// different values, and one loop iteration replaces four.  With `prune` (bounded 1-Lipschitz leaves, min / max
-// operators), the far test of a sphere / box runs ONCE, at the hit position c, against a threshold the caller widened
-// by the tap offset eps sqrt(3): a leaf that passes it is far from all four taps and is skipped for all of them.
-// Returns false when the program contains a SmoothUnion (see below) or the records do not form a valid program: the
-// kernel then taps one position at a time through map_scene_spec.
-inline bool generate_map_scene_taps(const std::vector<RmRecord>& rec, bool prune, std::string* out) {
     std::string s;
-    char line[768];
-    s += "namespace rmk {\n";
-    s += "template <bool FAST>\n";
-    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]) {\n";
-    if (prune) {
-        s += "    const float thrk = thr * 1.000005f;\n";
-        s += "    const float thr2k = (thr * thr) * 1.00001f;\n";
-        s += "    const float inf = __uint_as_float(0x7F800000u);\n";
+    char line[1024];
+    s += "namespace rmk {\ntemplate <bool FAST>\n";
+    if (T == 1) {
+        s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, unsigned long long need, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
+        if (prune) s += "    const float inf = __uint_as_float(0x7F800000u);\n";
+        s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
+    } else {
+        s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, unsigned long long need, unsigned long long live, SqrtGuard& tiny, float (&f)[4]) {\n";
+        if (prune) s += "    const float inf = __uint_as_float(0x7F800000u);\n";
+        s += "    const float e = 0.0001f;\n";  // wgsl:136; k = (1,-1): taps (+,-,-), (-,-,+), (-,+,-), (+,+,+) (wgsl:138-141)
+        s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
+        s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
+        s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
     }
-    const bool fence = jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;  // A/B: see guard_fence (rm_kernel_v5.h)
-    s += "    const float e = 0.0001f;\n";  // wgsl:136; k = (1,-1): taps (+,-,-), (-,-,+), (-,+,-), (+,+,+) (wgsl:138-141)
-    s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
-    s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
-    s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
-    if (prune) {  // group tests up front, as in generate_map_scene
-        int total = 0;
-        for (const RmRecord& r : rec) total += RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX;
-        for (int g = 0; 2 * g + 1 < total; g++) {
-            const unsigned goff = (unsigned)(rec.size() + (size_t)g) * 8u;
-            std::snprintf(line, sizeof line, "    const bool g%d = spec_group_near(live, lp + %u, cx, cy, cz, thrk);\n", g, goff);
+    // names: value w at tap t, position scope c at tap t
+    auto V = [&](int w, int t) { char b[32]; if (T == 1) std::snprintf(b, sizeof b, "v%d", w); else std::snprintf(b, sizeof b, "v%d_%d", w, t); return std::string(b); };
+    auto P = [&](int c, int t) {
+        char b[96];
+        if (T == 1) std::snprintf(b, sizeof b, "x%d, y%d, z%d", c, c, c);
+        else std::snprintf(b, sizeof b, "x%d_%d, y%d_%d, z%d_%d", c, t, c, t, c, t);
+        return std::string(b);
+    };
+    auto leaf_fn = [](uint32_t kind) -> const char* {
+        return kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>" : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>"
+             : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
+    };
+    auto leaf_expr = [&](size_t i, int c, int t) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op);
+        char b[256];
+        if (kind == RM_KIND_PLANE) std::snprintf(b, sizeof b, "%s(lp + %u, %s)", leaf_fn(kind), (unsigned)i * 8u, P(c, t).c_str());
+        else std::snprintf(b, sizeof b, "%s(lp + %u, %s, tiny)", leaf_fn(kind), (unsigned)i * 8u, P(c, t).c_str());
+        return std::string(b);
+    };
+    auto op_name = [](uint32_t mode) -> const char* { return mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr; };
+    // w = smooth_union(record koff; a, b): the T values at once (T = 4: ONE blend-zone test for the four taps, spec_smooth_union4)
+    auto emit_smooth = [&](const char* decl, int w, unsigned koff, const std::vector<std::string>& a, const std::vector<std::string>& b, const char* ind) {
+        if (T == 1) {
+            std::snprintf(line, sizeof line, "%s%s%s = spec_smooth_union(lp + %u, %s, %s, live);\n", ind, decl, V(w, 0).c_str(), koff, a[0].c_str(), b[0].c_str());
+            s += line;
+            return;
+        }
+        if (decl[0]) {
+            std::snprintf(line, sizeof line, "%sfloat %s, %s, %s, %s;\n", ind, V(w, 0).c_str(), V(w, 1).c_str(), V(w, 2).c_str(), V(w, 3).c_str());
             s += line;
         }
-    }
-    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
-    int leaves = 0, nv = 0, np = 0;
-    int n_pruned_total = 0, n_pruned = 0;  // grouped far tests, as in generate_map_scene
-    for (const RmRecord& r : rec) n_pruned_total += prune && (RM_OP_KIND(r.op) == RM_KIND_SPHERE || RM_OP_KIND(r.op) == RM_KIND_BOX);
-    std::vector<int> stack;
-    std::vector<int> pos;  // open transform scopes, as in generate_map_scene
+        std::snprintf(line, sizeof line,
+                      "%s{ const float sa[4] = {%s, %s, %s, %s}, sb[4] = {%s, %s, %s, %s}; float so[4];\n"
+                      "%s  spec_smooth_union4(lp + %u, sa, sb, live, so); %s = so[0]; %s = so[1]; %s = so[2]; %s = so[3]; }\n",
+                      ind, a[0].c_str(), a[1].c_str(), a[2].c_str(), a[3].c_str(), b[0].c_str(), b[1].c_str(), b[2].c_str(), b[3].c_str(),
+                      ind, koff, V(w, 0).c_str(), V(w, 1).c_str(), V(w, 2).c_str(), V(w, 3).c_str());
+        s += line;
+    };
+    auto names = [&](int w) { std::vector<std::string> n; for (int t = 0; t < T; t++) n.push_back(V(w, t)); return n; };
+
+    std::vector<int> stack;  // value numbers; back() is the accumulator
+    std::vector<int> pos;    // position numbers of the open transform scopes; back() is the current one
     pos.push_back(0);
-    for (size_t i = 0; i < rec.size(); i++) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u;
-        if (kind == RM_KIND_XFORM) {
-            if (prune) return false;  // pruned programs have no transforms
-            const int c = pos.back();
-            if ((mode & 1u) == 0u) {
-                const int n = ++np;
-                for (int t = 0; t < 4; t++) {
-                    if (mode == RM_XF_T_PUSH)
-                        std::snprintf(line, sizeof line, "    const float x%d_%d = x%d_%d - lp[%u], y%d_%d = y%d_%d - lp[%u], z%d_%d = z%d_%d - lp[%u];\n",
-                                      n, t, c, t, off, n, t, c, t, off + 1u, n, t, c, t, off + 2u);
-                    else if (mode == RM_XF_R_PUSH)
-                        std::snprintf(line, sizeof line, "    float x%d_%d = x%d_%d, y%d_%d = y%d_%d, z%d_%d = z%d_%d; xf_rotate_conj(lp[%u], lp[%u], lp[%u], lp[%u], x%d_%d, y%d_%d, z%d_%d);\n",
-                                      n, t, c, t, n, t, c, t, n, t, c, t, off, off + 1u, off + 2u, off + 3u, n, t, n, t, n, t);
-                    else
-                        std::snprintf(line, sizeof line, "    const float x%d_%d = x%d_%d / lp[%u], y%d_%d = y%d_%d / lp[%u], z%d_%d = z%d_%d / lp[%u];\n",
-                                      n, t, c, t, off, n, t, c, t, off, n, t, c, t, off);
-                    s += line;
-                }
-                pos.push_back(n);
-            } else {
-                if (pos.size() < 2 || stack.empty()) return false;
-                pos.pop_back();
-                if (mode == RM_XF_S_POP) {
-                    const int a = stack.back(); stack.pop_back();
-                    const int w = nv++;
-                    for (int t = 0; t < 4; t++) {
-                        std::snprintf(line, sizeof line, "    const float v%d_%d = v%d_%d * lp[%u];\n", w, t, a, t, off);
+    int nv = 0, np = 0, leaves = 0;
+    auto after_leaf = [&](bool is_plane) {
+        if (fence && !is_plane) s += "    guard_fence(tiny);\n";
+        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
+    };
+    // records [first, last] as they stand (no unit inside): operators on the stack, leaves evaluated
+    auto emit_plain = [&](size_t first, size_t last, const char* ind) -> bool {
+        for (size_t i = first; i <= last; i++) {
+            const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+            const unsigned off = (unsigned)i * 8u;
+            if (kind == RM_KIND_MATERIAL) return false;  // (`rec` never holds tags)
+            if (kind == RM_KIND_XFORM) {  // space transformation: a new position value (push) or back to the enclosing one (pop)
+                const int c = pos.back();
+                if ((mode & 1u) == 0u) {
+                    const int n = ++np;
+                    for (int t = 0; t < T; t++) {
+                        char cx[24], cy[24], cz[24], nx[24], ny[24], nz[24];
+                        auto nm = [&](char* b, char a, int q) { if (T == 1) std::snprintf(b, 24, "%c%d", a, q); else std::snprintf(b, 24, "%c%d_%d", a, q, t); };
+                        nm(cx, 'x', c); nm(cy, 'y', c); nm(cz, 'z', c); nm(nx, 'x', n); nm(ny, 'y', n); nm(nz, 'z', n);
+                        if (mode == RM_XF_T_PUSH)
+                            std::snprintf(line, sizeof line, "%sconst float %s = %s - lp[%u], %s = %s - lp[%u], %s = %s - lp[%u];\n", ind, nx, cx, off, ny, cy, off + 1u, nz, cz, off + 2u);
+                        else if (mode == RM_XF_R_PUSH)
+                            std::snprintf(line, sizeof line, "%sfloat %s = %s, %s = %s, %s = %s; xf_rotate_conj(lp[%u], lp[%u], lp[%u], lp[%u], %s, %s, %s);\n",
+                                          ind, nx, cx, ny, cy, nz, cz, off, off + 1u, off + 2u, off + 3u, nx, ny, nz);
+                        else
+                            std::snprintf(line, sizeof line, "%sconst float %s = %s / lp[%u], %s = %s / lp[%u], %s = %s / lp[%u];\n", ind, nx, cx, off, ny, cy, off, nz, cz, off);
                         s += line;
                     }
-                    stack.push_back(w);
+                    pos.push_back(n);
+                } else {
+                    if (pos.size() < 2 || stack.empty()) return false;
+                    pos.pop_back();
+                    if (mode == RM_XF_S_POP) {
+                        const int a = stack.back(); stack.pop_back();
+                        const int w = nv++;
+                        for (int t = 0; t < T; t++) {
+                            std::snprintf(line, sizeof line, "%sconst float %s = %s * lp[%u];\n", ind, V(w, t).c_str(), V(a, t).c_str(), off);
+                            s += line;
+                        }
+                        stack.push_back(w);
+                    }
                 }
+                continue;
             }
-            continue;
-        }
-        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
-        if (kind == RM_KIND_POP) {
-            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            const int b = stack.back(); stack.pop_back();
-            const int a = stack.back(); stack.pop_back();
-            const int w = nv++;
-            if (mode == RM_MODE_SMOOTH) {
-                // SmoothUnion: left to itself the compiler interleaves the four copies of the correctly rounded division
-                // (~130 VGPRs, 3 waves per SIMD: 40 % slower than tapping one position at a time); spec_smooth_union4
-                // tests the blend zone once for the four taps and keeps one division in flight.
-                // RM_JIT_TAPS4_SMOOTH=0 restores the one-position taps.
-                const char* knob = std::getenv("RM_JIT_TAPS4_SMOOTH");
-                if (knob && std::atoi(knob) == 0) return false;
-                std::snprintf(line, sizeof line,
-                              "    float v%d_0, v%d_1, v%d_2, v%d_3;\n"
-                              "    { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3}, sb[4] = {v%d_0, v%d_1, v%d_2, v%d_3}; float so[4];\n"
-                              "      spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
-                              w, w, w, w, a, a, a, a, b, b, b, b, off, w, w, w, w);
-                s += line;
+            const char* op = op_name(mode);
+            if (kind == RM_KIND_POP) {
+                if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
+                const int b = stack.back(); stack.pop_back();
+                const int a = stack.back(); stack.pop_back();
+                const int w = nv++;
+                if (mode == RM_MODE_SMOOTH) {
+                    emit_smooth("const float ", w, off, names(a), names(b), ind);
+                } else {
+                    if (!op) return false;
+                    for (int t = 0; t < T; t++) {
+                        std::snprintf(line, sizeof line, "%sconst float %s = %s(%s, %s);\n", ind, V(w, t).c_str(), op, V(a, t).c_str(), V(b, t).c_str());
+                        s += line;
+                    }
+                }
                 stack.push_back(w);
                 continue;
             }
-            if (!op) return false;
-            for (int t = 0; t < 4; t++) {
-                std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, v%d_%d);\n", w, t, op, a, t, b, t);
-                s += line;
+            if (!leaf_fn(kind) || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;  // the decoder never fuses an operator with a parameter
+            int a = -1;
+            if (mode != RM_MODE_PUSH) {
+                if (stack.empty()) return false;
+                a = stack.back(); stack.pop_back();
             }
-            stack.push_back(w);
-            continue;
-        }
-        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
-                       : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
-        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
-        if (prune && kind == RM_KIND_PLANE) return false;
-        int a = -1;
-        if (mode != RM_MODE_PUSH) {
-            if (stack.empty()) return false;
-            a = stack.back(); stack.pop_back();
-        }
-        const int w = nv++;
-        const int c = pos.back();
-        const bool pruned = prune && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX);
-        if (pruned) {
-            for (int t = 0; t < 4; t++) {  // the value if the leaf is far: see generate_map_scene
-                if (mode == RM_MODE_PUSH || mode == RM_MODE_INTER) std::snprintf(line, sizeof line, "    float v%d_%d = inf;\n", w, t);
-                else std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d;\n", w, t, a, t);
-                s += line;
-            }
-            const int ordinal = n_pruned++, grp = ordinal / 2;
-            const char* guard = "";
-            char gname[32];
-            if ((ordinal | 1) < n_pruned_total) {
-                std::snprintf(gname, sizeof gname, "g%d && ", grp);
-                guard = gname;
-            }
-            if (kind == RM_KIND_SPHERE)
-                std::snprintf(line, sizeof line, "    if (%sspec_any_near(live, spec_sphere_far(lp + %u, spec_sphere_a(lp + %u, cx, cy, cz), thrk))) {\n", guard, off, off);
-            else
-                std::snprintf(line, sizeof line, "    if (%sspec_any_near(live, spec_box_a(lp + %u, cx, cy, cz).a > thr2k)) {\n", guard, off);
-            s += line;
-        }
-        for (int t = 0; t < 4; t++) {
-            char leaf[192];
-            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x%d_%d, y%d_%d, z%d_%d)", fn, off, c, t, c, t, c, t);
-            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x%d_%d, y%d_%d, z%d_%d, tiny)", fn, off, c, t, c, t, c, t);
-            const char* decl = pruned ? "    " : "const float ";
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    %sv%d_%d = %s;\n", decl, w, t, leaf);
-            else std::snprintf(line, sizeof line, "    %sv%d_%d = %s(v%d_%d, %s);\n", decl, w, t, op, a, t, leaf);
-            s += line;
-        }
-        if (pruned) s += "    }\n";
-        if (fence && kind != RM_KIND_PLANE) s += "    guard_fence(tiny);\n";  // see guard_fence (rm_kernel_v5.h)
-        stack.push_back(w);
-        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
-    }
-    if (stack.empty()) return false;
-    for (int t = 0; t < 4; t++) {
-        std::snprintf(line, sizeof line, "    f[%d] = v%d_%d;\n", t, stack.back(), t);
-        s += line;
-    }
-    s += "}\n}  // namespace rmk\n";
-    *out = std::move(s);
-    return true;
-}
-
-
-// ---- programs that blend: the LOCAL skipping rule (rm_groups.h, rm_kernel_v5.h spec_local_near) -----------------------
-// map_scene_spec for a program with SmoothUnion operators.  Everything is evaluated as generate_map_scene(prune = false)
-// would, except the leaves the local rule applies to (right operand of a Union, or of the SmoothUnion that follows): each
-// such leaf -- or a PAIR of them, blended into the same accumulator one after the other -- sits behind the wave-uniform test
-// "is its lower bound less than k above the accumulator for any live lane"; when it is not, leaf and operator are skipped
-// and the result is the accumulator, the very bits the evaluation would have produced.  Subtracted leaves keep the local
-// test of the lattice form (spec_sub_*_near), which needs no threshold either.  `thr` carries only the float margin m.
-inline bool generate_map_scene_blend(const std::vector<RmRecord>& rec, std::string* out) {
-    const int count_mode = jit_knob("RM_JIT_PRUNE_STATS", 0);  // 1 leaves evaluated, 3 near pairs
-    const char* counted = count_mode == 1 ? "n_eval += 1u; " : "";
-    // members of a near pair: 0 untested (default; measured, config 3 at 4K: 4.86 ms against 5.01 with a test each: a box's test
-    // needs 14 of the box's 26 vector instructions first), 1 a test each, 2 boxes only, 3 spheres only; leaves without a partner
-    // always have one
-    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);
-    const bool upfront = jit_knob("RM_JIT_BLEND_UPFRONT", 1) != 0;  // the pairs' squared distances at the top (their LDS reads go out together)
-    const bool sub_tests = jit_knob("RM_JIT_SUB_TESTS", 1) != 0;
-    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
-    const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
-    std::map<int, int> pair_of_first;
-    for (size_t g = 0; g < pairs.size(); g++) pair_of_first[pairs[g].first] = (int)g;
-    std::string s;
-    char line[768];
-    s += "namespace rmk {\n";
-    s += "template <bool FAST>\n";
-    s += "RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n";
-    s += "    const float m = thr;\n";  // the float margin of the local rule; a blend kernel's body passes no threshold
-    s += "    const float x0 = qx, y0 = qy, z0 = qz;\n";
-    auto pair_distance = [&](int g) {
-        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, x0, y0, z0, kr%d);\n", g, g,
-                      (unsigned)(rec.size() + (size_t)g) * 8u, g);
-        s += line;
-    };
-    if (upfront)
-        for (size_t g = 0; g < pairs.size(); g++) pair_distance((int)g);
-    std::vector<int> stack;
-    int nv = 0, leaves = 0;
-    auto barrier = [&]() {
-        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
-    };
-    // one local leaf and its operator: v<w> (declared by the caller, = v<a>) becomes op(v<a>, leaf) unless the leaf is skipped
-    auto emit_member = [&](size_t i, const RmLeafUse& use, int a, int w, bool test) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op);
-        const unsigned off = (unsigned)i * 8u, koff = use.k_rec >= 0 ? (unsigned)use.k_rec * 8u : 0u;
-        char kexpr[64], open_apply[96];
-        if (use.k_rec >= 0) {
-            std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", koff);
-            std::snprintf(open_apply, sizeof open_apply, "spec_smooth_union(lp + %u, v%d, ", koff, a);
-        } else {
-            std::snprintf(kexpr, sizeof kexpr, "0.0f");
-            std::snprintf(open_apply, sizeof open_apply, "vmin(v%d, ", a);
-        }
-        const char* close_apply = use.k_rec >= 0 ? ", live)" : ")";
-        if (kind == RM_KIND_SPHERE) {
-            if (test)
-                std::snprintf(line, sizeof line,
-                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_local_near(live, a, ((v%d + m) + %s) + lp[%u])) { v%d = %sspec_sphere_v<FAST>(lp + %u, a, tiny)%s; %s} }\n",
-                              off, a, kexpr, off + 3u, w, open_apply, off, close_apply, counted);
-            else
-                std::snprintf(line, sizeof line, "    { v%d = %sspec_sphere<FAST>(lp + %u, x0, y0, z0, tiny)%s; %s}\n", w, open_apply, off, close_apply, counted);
-        } else {
-            if (test)
-                std::snprintf(line, sizeof line,
-                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_local_box_near(live, b.a, (v%d + m) + %s)) { v%d = %sspec_box_v<FAST>(b, tiny)%s; %s} }\n",
-                              off, a, kexpr, w, open_apply, close_apply, counted);
-            else
-                std::snprintf(line, sizeof line, "    { v%d = %sspec_box<FAST>(lp + %u, x0, y0, z0, tiny)%s; %s}\n", w, open_apply, off, close_apply, counted);
-        }
-        s += line;
-    };
-    auto wants_test = [&](uint32_t kind) {
-        return leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
-    };
-    for (size_t i = 0; i < rec.size(); i++) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u;
-        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL) return false;  // the local rule is generated for world-space leaves only
-        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
-        if (kind == RM_KIND_POP) {
-            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            const int b = stack.back(); stack.pop_back();
-            const int a = stack.back(); stack.pop_back();
             const int w = nv++;
-            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float v%d = spec_smooth_union(lp + %u, v%d, v%d, live);\n", w, off, a, b);
-            else if (op) std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, v%d);\n", w, op, a, b);
-            else return false;
-            s += line;
-            stack.push_back(w);
-            continue;
-        }
-        const RmLeafUse use = rm_leaf_use(rec, i);
-        if (use.local) {
-            if (stack.empty()) return false;
-            const int a = stack.back(); stack.pop_back();
-            auto pf = pair_of_first.find((int)i);
-            if (pf != pair_of_first.end()) {
-                const int g = pf->second;
-                const size_t j = (size_t)pairs[(size_t)g].second;
-                const RmLeafUse use2 = rm_leaf_use(rec, j);
-                const int w1 = nv++, w2 = nv++;
-                std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n", w1, a, w2, a);
+            for (int t = 0; t < T; t++) {
+                if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "%sconst float %s = %s;%s\n", ind, V(w, t).c_str(), leaf_expr(i, pos.back(), t).c_str(), counted);
+                else std::snprintf(line, sizeof line, "%sconst float %s = %s(%s, %s);%s\n", ind, V(w, t).c_str(), op, V(a, t).c_str(), leaf_expr(i, pos.back(), t).c_str(), counted);
                 s += line;
-                if (!upfront) pair_distance(g);
-                std::snprintf(line, sizeof line, "    if (spec_local_near(live, pa%d, (v%d + m) + kr%d)) {\n%s", g, a, g, count_mode == 3 ? "    n_eval += 1u;\n" : "");
-                s += line;
-                emit_member(i, use, a, w1, wants_test(kind));
-                std::snprintf(line, sizeof line, "    v%d = v%d;\n", w2, w1);
-                s += line;
-                emit_member(j, use2, w1, w2, wants_test(RM_OP_KIND(rec[j].op)));
-                s += "    }\n";
-                stack.push_back(w2);
-                barrier();
-                barrier();
-                i = (size_t)use2.next - 1u;
-            } else {
-                const int w = nv++;
-                std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
-                s += line;
-                emit_member(i, use, a, w, true);
-                stack.push_back(w);
-                barrier();
-                i = (size_t)use.next - 1u;
-            }
-            continue;
-        }
-        if (mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
-        int a = -1;
-        if (mode != RM_MODE_PUSH) {
-            if (stack.empty()) return false;
-            a = stack.back(); stack.pop_back();
-        }
-        const int w = nv++;
-        if (mode == RM_MODE_SUB && sub_tests && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX)) {  // see generate_map_scene
-            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, a);
-            s += line;
-            if (kind == RM_KIND_SPHERE)
-                std::snprintf(line, sizeof line,
-                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) { v%d = vmax_negb(v%d, spec_sphere_v<FAST>(lp + %u, a, tiny)); %s} }\n",
-                              off, off, a, w, a, off, counted);
-            else
-                std::snprintf(line, sizeof line,
-                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_sub_box_near(live, b.a, v%d)) { v%d = vmax_negb(v%d, spec_box_v<FAST>(b, tiny)); %s} }\n",
-                              off, a, w, a, counted);
-            s += line;
-        } else {
-            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
-                           : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
-            if (!fn) return false;
-            char leaf[128];
-            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0, y0, z0)", fn, off);
-            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0, y0, z0, tiny)", fn, off);
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d = %s; %s\n", w, leaf, counted);
-            else std::snprintf(line, sizeof line, "    const float v%d = %s(v%d, %s); %s\n", w, op, a, leaf, counted);
-            s += line;
-        }
-        stack.push_back(w);
-        barrier();
-    }
-    if (stack.empty()) return false;
-    std::snprintf(line, sizeof line, "    return v%d;\n}\n}  // namespace rmk\n", stack.back());
-    s += line;
-    *out = std::move(s);
-    return true;
-}
-
-// The four taps of a hit for a program that blends (see generate_map_scene_taps): the local rule is tested ONCE per leaf or
-// pair, with the bound taken at the hit position c -- eps sqrt(3) from every tap: the caller's margin `thr` carries it --
-// against each tap's own accumulator; a leaf is skipped only when it is far for all four taps of every live lane.
-inline bool generate_map_scene_taps_blend(const std::vector<RmRecord>& rec, std::string* out) {
-    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);
-    const bool fence = jit_knob("RM_JIT_GUARD_FENCE", 1) != 0;
-    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER_TAPS") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER_TAPS")) : 2;
-    const char* knob = std::getenv("RM_JIT_TAPS4_SMOOTH");
-    if (knob && std::atoi(knob) == 0) return false;
-    const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
-    std::map<int, int> pair_of_first;
-    for (size_t g = 0; g < pairs.size(); g++) pair_of_first[pairs[g].first] = (int)g;
-    std::string s;
-    char line[1024];
-    s += "namespace rmk {\n";
-    s += "template <bool FAST>\n";
-    s += "RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]) {\n";
-    s += "    const float m = thr;\n";
-    s += "    const float e = 0.0001f;\n";
-    s += "    const float x0_0 = cx + e, x0_1 = cx - e, x0_2 = cx - e, x0_3 = cx + e;\n";
-    s += "    const float y0_0 = cy - e, y0_1 = cy - e, y0_2 = cy + e, y0_3 = cy + e;\n";
-    s += "    const float z0_0 = cz - e, z0_1 = cz + e, z0_2 = cz - e, z0_3 = cz + e;\n";
-    for (size_t g = 0; g < pairs.size(); g++) {
-        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, cx, cy, cz, kr%d);\n", (int)g, (int)g,
-                      (unsigned)(rec.size() + g) * 8u, (int)g);
-        s += line;
-    }
-    std::vector<int> stack;
-    int nv = 0, leaves = 0;
-    auto barrier = [&]() {
-        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
-    };
-    auto apply4 = [&](const RmLeafUse& use, int a, int w, const char* leaf_fmt_fn, unsigned off) {
-        // v<w>_t = op(v<a>_t, leaf(tap t)) for the four taps
-        if (use.k_rec >= 0) {
-            std::snprintf(line, sizeof line,
-                          "      { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3};\n"
-                          "        const float sb[4] = {%s(lp + %u, x0_0, y0_0, z0_0, tiny), %s(lp + %u, x0_1, y0_1, z0_1, tiny), %s(lp + %u, x0_2, y0_2, z0_2, tiny), %s(lp + %u, x0_3, y0_3, z0_3, tiny)};\n"
-                          "        float so[4]; spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
-                          a, a, a, a, leaf_fmt_fn, off, leaf_fmt_fn, off, leaf_fmt_fn, off, leaf_fmt_fn, off, (unsigned)use.k_rec * 8u, w, w, w, w);
-            s += line;
-        } else {
-            for (int t = 0; t < 4; t++) {
-                std::snprintf(line, sizeof line, "      v%d_%d = vmin(v%d_%d, %s(lp + %u, x0_%d, y0_%d, z0_%d, tiny));\n", w, t, a, t, leaf_fmt_fn, off, t, t, t);
-                s += line;
-            }
-        }
-    };
-    auto emit_member = [&](size_t i, const RmLeafUse& use, int a, int w, bool test) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op);
-        const unsigned off = (unsigned)i * 8u;
-        char kexpr[64];
-        if (use.k_rec >= 0) std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", (unsigned)use.k_rec * 8u);
-        else std::snprintf(kexpr, sizeof kexpr, "0.0f");
-        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : "spec_box<FAST>";
-        if (test) {
-            if (kind == RM_KIND_SPHERE)
-                std::snprintf(line, sizeof line,
-                              "    { const float kq = %s + lp[%u]; const float rh[4] = {(v%d_0 + m) + kq, (v%d_1 + m) + kq, (v%d_2 + m) + kq, (v%d_3 + m) + kq};\n"
-                              "      if (spec_local_near4(live, spec_sphere_a(lp + %u, cx, cy, cz), rh, true)) {\n", kexpr, off + 3u, a, a, a, a, off);
-            else
-                std::snprintf(line, sizeof line,
-                              "    { const float kq = %s; const float rh[4] = {(v%d_0 + m) + kq, (v%d_1 + m) + kq, (v%d_2 + m) + kq, (v%d_3 + m) + kq};\n"
-                              "      if (spec_local_near4(live, spec_box_a(lp + %u, cx, cy, cz).a, rh, false)) {\n", kexpr, a, a, a, a, off);
-            s += line;
-            apply4(use, a, w, fn, off);
-            s += "      } }\n";
-        } else {
-            s += "    {\n";
-            apply4(use, a, w, fn, off);
-            s += "    }\n";
-        }
-        if (fence) s += "    guard_fence(tiny);\n";
-    };
-    auto wants_test = [&](uint32_t kind) {
-        return leaf_tests == 1 || (leaf_tests == 2 && kind == RM_KIND_BOX) || (leaf_tests == 3 && kind == RM_KIND_SPHERE);
-    };
-    for (size_t i = 0; i < rec.size(); i++) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        const unsigned off = (unsigned)i * 8u;
-        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL) return false;
-        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
-        if (kind == RM_KIND_POP) {
-            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            const int b = stack.back(); stack.pop_back();
-            const int a = stack.back(); stack.pop_back();
-            const int w = nv++;
-            if (mode == RM_MODE_SMOOTH) {
-                std::snprintf(line, sizeof line,
-                              "    float v%d_0, v%d_1, v%d_2, v%d_3;\n"
-                              "    { const float sa[4] = {v%d_0, v%d_1, v%d_2, v%d_3}, sb[4] = {v%d_0, v%d_1, v%d_2, v%d_3}; float so[4];\n"
-                              "      spec_smooth_union4(lp + %u, sa, sb, live, so); v%d_0 = so[0]; v%d_1 = so[1]; v%d_2 = so[2]; v%d_3 = so[3]; }\n",
-                              w, w, w, w, a, a, a, a, b, b, b, b, off, w, w, w, w);
-                s += line;
-            } else {
-                if (!op) return false;
-                for (int t = 0; t < 4; t++) {
-                    std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, v%d_%d);\n", w, t, op, a, t, b, t);
-                    s += line;
-                }
             }
             stack.push_back(w);
-            continue;
+            after_leaf(kind == RM_KIND_PLANE);
         }
-        const RmLeafUse use = rm_leaf_use(rec, i);
-        if (use.local) {
-            if (stack.empty()) return false;
-            const int a = stack.back(); stack.pop_back();
-            auto pf = pair_of_first.find((int)i);
-            if (pf != pair_of_first.end()) {
-                const int g = pf->second;
-                const size_t j = (size_t)pairs[(size_t)g].second;
-                const RmLeafUse use2 = rm_leaf_use(rec, j);
-                const int w1 = nv++, w2 = nv++;
-                for (int t = 0; t < 4; t++) {
-                    std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d, v%d_%d = v%d_%d;\n", w1, t, a, t, w2, t, a, t);
-                    s += line;
-                }
-                std::snprintf(line, sizeof line,
-                              "    { const float rh[4] = {(v%d_0 + m) + kr%d, (v%d_1 + m) + kr%d, (v%d_2 + m) + kr%d, (v%d_3 + m) + kr%d};\n"
-                              "    if (spec_local_near4(live, pa%d, rh, true)) {\n", a, g, a, g, a, g, a, g, g);
-                s += line;
-                emit_member(i, use, a, w1, wants_test(kind));
-                for (int t = 0; t < 4; t++) {
-                    std::snprintf(line, sizeof line, "    v%d_%d = v%d_%d;\n", w2, t, w1, t);
-                    s += line;
-                }
-                emit_member(j, use2, w1, w2, wants_test(RM_OP_KIND(rec[j].op)));
-                s += "    } }\n";
-                stack.push_back(w2);
-                barrier();
-                barrier();
-                i = (size_t)use2.next - 1u;
-            } else {
-                const int w = nv++;
-                for (int t = 0; t < 4; t++) {
-                    std::snprintf(line, sizeof line, "    float v%d_%d = v%d_%d;\n", w, t, a, t);
-                    s += line;
-                }
-                emit_member(i, use, a, w, true);
-                stack.push_back(w);
-                barrier();
-                i = (size_t)use.next - 1u;
-            }
-            continue;
-        }
-        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>"
-                       : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : kind == RM_KIND_PLANE ? "spec_plane" : nullptr;
-        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
-        int a = -1;
-        if (mode != RM_MODE_PUSH) {
-            if (stack.empty()) return false;
-            a = stack.back(); stack.pop_back();
-        }
-        const int w = nv++;
-        for (int t = 0; t < 4; t++) {
-            char leaf[192];
-            if (kind == RM_KIND_PLANE) std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0_%d, y0_%d, z0_%d)", fn, off, t, t, t);
-            else std::snprintf(leaf, sizeof leaf, "%s(lp + %u, x0_%d, y0_%d, z0_%d, tiny)", fn, off, t, t, t);
-            if (mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "    const float v%d_%d = %s;\n", w, t, leaf);
-            else std::snprintf(line, sizeof line, "    const float v%d_%d = %s(v%d_%d, %s);\n", w, t, op, a, t, leaf);
-            s += line;
-        }
-        if (fence && kind != RM_KIND_PLANE) s += "    guard_fence(tiny);\n";
-        stack.push_back(w);
-        barrier();
-    }
-    if (stack.empty()) return false;
-    for (int t = 0; t < 4; t++) {
-        std::snprintf(line, sizeof line, "    f[%d] = v%d_%d;\n", t, stack.back(), t);
-        s += line;
-    }
-    s += "}\n}  // namespace rmk\n";
-    *out = std::move(s);
-    return true;
-}
+        return true;
+    };
 
-
-// ---- programs that blend, skip sets carried along the ray (rm_kernel_v5.h "Skip sets carried ALONG a ray") ---------------
-// The top level of the program as a chain of UNITS, each starting and ending with one value (the accumulator) on the stack:
-enum : int { BU_START = 0,    // record 0: the leaf that starts the chain
-             BU_SINGLE = 1,   // a local leaf (rm_groups.h) and its Union / SmoothUnion
-             BU_PAIR = 2,     // two of them, tested together
-             BU_SUB = 3,      // a sphere / box fused with a Subtraction: the local test of the lattice form
-             BU_GENERIC = 4 };// anything else that takes the accumulator to its next value: a fused Intersection / cylinder / plane,
-                              // or a sub-tree (pushed, built, popped into the chain by its operator)
-struct BlendUnit { int kind, first, last, second; };  // records [first, last]; second: the pair's second leaf record
-inline bool blend_units(const std::vector<RmRecord>& rec, std::vector<BlendUnit>* out) {
-    if (rec.empty() || RM_OP_MODE(rec[0].op) != RM_MODE_PUSH || (rec[0].op & RM_OP_SPILL)) return false;
-    const uint32_t k0 = RM_OP_KIND(rec[0].op);
-    if (k0 != RM_KIND_SPHERE && k0 != RM_KIND_BOX && k0 != RM_KIND_CYLINDER) return false;
-    std::vector<BlendUnit> u;
-    u.push_back({BU_START, 0, 0, -1});
-    std::map<int, int> second_of;
-    for (const std::pair<int, int>& pr : rm_blend_pairs(rec)) second_of[pr.first] = pr.second;
-    for (size_t i = 1; i < rec.size();) {
-        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
-        if (kind == RM_KIND_XFORM || kind == RM_KIND_MATERIAL || kind == RM_KIND_PLANE || kind == RM_KIND_POP) return false;  // (a POP at depth 1 cannot be)
-        const RmLeafUse use = rm_leaf_use(rec, i);
-        if (use.local) {
-            auto it = second_of.find((int)i);
-            if (it != second_of.end()) {
-                const RmLeafUse use2 = rm_leaf_use(rec, (size_t)it->second);
-                u.push_back({BU_PAIR, (int)i, use2.next - 1, it->second});
-                i = (size_t)use2.next;
-            } else {
-                u.push_back({BU_SINGLE, (int)i, use.next - 1, -1});
-                i = (size_t)use.next;
-            }
-            continue;
-        }
-        if (mode != RM_MODE_PUSH) {  // a leaf fused with its operator
-            u.push_back({mode == RM_MODE_SUB && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX) ? BU_SUB : BU_GENERIC, (int)i, (int)i, -1});
+    for (size_t i = 0; i < rec.size();) {
+        const int ui = unit_at[i];
+        if (ui < 0) {
+            if (!emit_plain(i, i, "    ")) return false;
             i++;
             continue;
         }
-        // a pushed leaf that is not a local one: the start of a sub-tree; the unit ends with the operator that pops the chain's
-        // accumulator back (stack depth, counted from the accumulator = 1, returns to 1)
-        int depth = 1;
-        size_t j = i;
-        for (; j < rec.size(); j++) {
-            const uint32_t kj = RM_OP_KIND(rec[j].op), mj = RM_OP_MODE(rec[j].op);
-            if (kj == RM_KIND_XFORM || kj == RM_KIND_MATERIAL || kj == RM_KIND_PLANE) return false;
-            if (kj == RM_KIND_POP) depth--;
-            else if (mj == RM_MODE_PUSH) depth++;
-            if (depth == 1) break;
-        }
-        if (j == rec.size()) return false;  // the program ends with more than one value: not a chain
-        u.push_back({BU_GENERIC, (int)i, (int)j, -1});
-        i = j + 1;
-    }
-    // worth it from a handful of units on; one bit per unit
-    const int min_units = jit_knob("RM_JIT_CACHED_MIN_UNITS", 4);
-    if ((int)u.size() < min_units || u.size() > 64) return false;
-    *out = std::move(u);
-    return true;
-}
-
-// Plain code for records [first, last] of `rec` on a stack of named values (as generate_map_scene without pruning); used for
-// the generic units.  `pfx` prefixes the value names so that two units never collide.
-inline bool emit_plain_records(const std::vector<RmRecord>& rec, int first, int last, std::vector<std::string>& stack, const char* pfx,
-                               const char* counted, std::string& s) {
-    char line[768];
-    int nv = 0;
-    for (int i = first; i <= last; i++) {
-        const uint32_t kind = RM_OP_KIND(rec[(size_t)i].op), mode = RM_OP_MODE(rec[(size_t)i].op);
-        const unsigned off = (unsigned)i * 8u;
-        const char* op = mode == RM_MODE_UNION ? "vmin" : mode == RM_MODE_SUB ? "vmax_negb" : mode == RM_MODE_INTER ? "fmax_" : nullptr;
-        char w[48];
-        std::snprintf(w, sizeof w, "%s%d", pfx, nv++);
-        if (kind == RM_KIND_POP) {
-            if (stack.size() < 2 || mode == RM_MODE_PUSH) return false;
-            const std::string b = stack.back(); stack.pop_back();
-            const std::string a = stack.back(); stack.pop_back();
-            if (mode == RM_MODE_SMOOTH) std::snprintf(line, sizeof line, "    const float %s = spec_smooth_union(lp + %u, %s, %s, live);\n", w, off, a.c_str(), b.c_str());
-            else if (op) std::snprintf(line, sizeof line, "    const float %s = %s(%s, %s);\n", w, op, a.c_str(), b.c_str());
-            else return false;
+        const RmUnit& u = units[(size_t)ui];
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        const int c = pos.back();
+        if (u.kind == RM_UNIT_OPAQUE) {
+            // an opaque stretch of the chain: from the accumulator to its next value; evaluated unless it is dead
+            if (stack.empty()) return false;
+            const int a = stack.back();
+            const int w = nv++;
+            for (int t = 0; t < T; t++) { std::snprintf(line, sizeof line, "    float %s = %s;\n", V(w, t).c_str(), V(a, t).c_str()); s += line; }
+            std::snprintf(line, sizeof line, "    if (unit_needed(need, %du)) {\n", ui);
             s += line;
-            stack.push_back(w);
+            const size_t depth0 = stack.size();
+            if (!emit_plain((size_t)u.first, (size_t)u.last, "        ") || stack.size() != depth0) return false;
+            for (int t = 0; t < T; t++) { std::snprintf(line, sizeof line, "        %s = %s;\n", V(w, t).c_str(), V(stack.back(), t).c_str()); s += line; }
+            s += "    }\n";
+            stack.back() = w;
+            i = (size_t)u.last + 1u;
             continue;
         }
-        const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>" : kind == RM_KIND_CYLINDER ? "spec_cylinder<FAST>" : nullptr;
-        if (!fn || mode == RM_MODE_SMOOTH || (mode != RM_MODE_PUSH && !op)) return false;
-        if (mode == RM_MODE_PUSH) {
-            std::snprintf(line, sizeof line, "    const float %s = %s(lp + %u, x0, y0, z0, tiny); %s\n", w, fn, off, counted);
-        } else {
+        // a unit that is one leaf: skipped, the result is +inf where the leaf would be pushed (or intersected with, in a lattice
+        // program: max(acc, +inf)), else the accumulator
+        const bool with_smooth = u.k_rec >= 0;  // "leaf; SmoothUnion": two records
+        const uint32_t eff_mode = with_smooth ? (uint32_t)RM_MODE_SMOOTH : mode;
+        int a = -1;
+        if (eff_mode != RM_MODE_PUSH) {
             if (stack.empty()) return false;
-            const std::string a = stack.back(); stack.pop_back();
-            std::snprintf(line, sizeof line, "    const float %s = %s(%s, %s(lp + %u, x0, y0, z0, tiny)); %s\n", w, op, a.c_str(), fn, off, counted);
+            a = stack.back(); stack.pop_back();
         }
+        const int w = nv++;
+        const bool to_inf = eff_mode == RM_MODE_PUSH || (eff_mode == RM_MODE_INTER && u.kind == RM_UNIT_LEAF);
+        for (int t = 0; t < T; t++) {
+            if (to_inf) std::snprintf(line, sizeof line, "    float %s = inf;\n", V(w, t).c_str());
+            else std::snprintf(line, sizeof line, "    float %s = %s;\n", V(w, t).c_str(), V(a, t).c_str());
+            s += line;
+        }
+        std::snprintf(line, sizeof line, "    if (unit_needed(need, %du)) {%s\n", ui, counted);
         s += line;
-        stack.push_back(w);
-    }
-    return true;
-}
-
-inline bool generate_blend_cached(const std::vector<RmRecord>& rec, std::string* out) {
-    std::vector<BlendUnit> units;
-    if (!blend_units(rec, &units)) return false;
-    const int count_mode = jit_knob("RM_JIT_PRUNE_STATS", 0);  // 1 leaves evaluated
-    const char* counted = count_mode == 1 ? "n_eval += 1u; " : "";
-    const int leaf_tests = jit_knob("RM_JIT_BLEND_LEAF_TESTS", 0);  // members of a near pair in a REFRESH: 0 untested (default), 1 tested
-    const int sched_every = std::getenv("RM_JIT_SCHED_BARRIER") ? std::atoi(std::getenv("RM_JIT_SCHED_BARRIER")) : 4;
-    std::map<int, int> pair_index;  // first leaf record -> index of the pair's group record
-    {
-        const std::vector<std::pair<int, int>> pairs = rm_blend_pairs(rec);
-        for (size_t g = 0; g < pairs.size(); g++) pair_index[pairs[g].first] = (int)g;
-    }
-    char line[1024];
-    std::string r, c;  // refresh, cached
-    r += "namespace rmk {\ntemplate <bool FAST>\n"
-         "RM_DEV float map_scene_refresh(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval, SpecCache& cache) {\n"
-         "    const float m = thr;\n    const float x0 = qx, y0 = qy, z0 = qz;\n    float rbud = __uint_as_float(0x7F800000u);\n";
-    c += "namespace rmk {\ntemplate <bool FAST>\n"
-         "RM_DEV float map_scene_cached(LdsF lp, float qx, float qy, float qz, unsigned long long skip, uint32_t jstar, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n"
-         "    const float x0 = qx, y0 = qy, z0 = qz;\n";
-    for (auto& kv : pair_index) {
-        std::snprintf(line, sizeof line, "    float kr%d; const float pa%d = spec_pair_a(lp + %u, x0, y0, z0, kr%d);\n", kv.second, kv.second,
-                      (unsigned)(rec.size() + (size_t)kv.second) * 8u, kv.second);
-        r += line;
-    }
-    int leaves = 0;
-    auto barrier = [&](std::string& s) {
-        if (sched_every > 0 && ++leaves % sched_every == 0) s += "    __builtin_amdgcn_sched_barrier(0);\n";
-    };
-    // a local member (leaf record i) in the refresh: vW (declared by the caller, = vA) becomes op(vA, leaf) unless its own test
-    // skips it; an evaluated member is a restart candidate
-    auto refresh_member = [&](size_t i, int a, int w, bool test, unsigned long long bit_if_single) {
-        const RmLeafUse use = rm_leaf_use(rec, i);
-        const uint32_t kind = RM_OP_KIND(rec[i].op);
-        const unsigned off = (unsigned)i * 8u, koff = use.k_rec >= 0 ? (unsigned)use.k_rec * 8u : 0u;
-        char kexpr[64], apply_open[96];
-        if (use.k_rec >= 0) {
-            std::snprintf(kexpr, sizeof kexpr, "spec_local_k(lp + %u)", koff);
-            std::snprintf(apply_open, sizeof apply_open, "spec_smooth_union(lp + %u, v%d, ", koff, a);
-        } else {
-            std::snprintf(kexpr, sizeof kexpr, "0.0f");
-            std::snprintf(apply_open, sizeof apply_open, "vmin(v%d, ", a);
-        }
-        const char* apply_close = use.k_rec >= 0 ? ", live)" : ")";
-        std::snprintf(line, sizeof line, "    { const float kk = %s;\n", kexpr);
-        r += line;
-        if (kind == RM_KIND_SPHERE) {
-            if (test) {
-                std::snprintf(line, sizeof line,
-                              "      const float a = spec_sphere_a(lp + %u, x0, y0, z0); const float rhs = ((v%d + m) + kk) + lp[%u];\n"
-                              "      if (spec_local_near(live, a, rhs)) { const float t = spec_sphere_v<FAST>(lp + %u, a, tiny); %s\n"
-                              "        spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s; }\n",
-                              off, a, off + 3u, off, counted, (unsigned)i, a, w, apply_open, apply_close);
-                r += line;
-                if (bit_if_single) {
-                    std::snprintf(line, sizeof line, "      else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(a) - rhs) * 0.5f);\n", bit_if_single);
-                    r += line;
-                }
-            } else {
-                std::snprintf(line, sizeof line, "      const float t = spec_sphere<FAST>(lp + %u, x0, y0, z0, tiny); %s\n"
-                              "      spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s;\n", off, counted, (unsigned)i, a, w, apply_open, apply_close);
-                r += line;
-            }
-        } else {
-            if (test) {
-                std::snprintf(line, sizeof line,
-                              "      const SpecBox b = spec_box_a(lp + %u, x0, y0, z0); const float rhs = (v%d + m) + kk;\n"
-                              "      if (spec_local_box_near(live, b.a, rhs)) { const float t = spec_box_v<FAST>(b, tiny); %s\n"
-                              "        spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s; }\n",
-                              off, a, counted, (unsigned)i, a, w, apply_open, apply_close);
-                r += line;
-                if (bit_if_single) {
-                    std::snprintf(line, sizeof line, "      else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(b.a) - rhs) * 0.5f);\n", bit_if_single);
-                    r += line;
-                }
-            } else {
-                std::snprintf(line, sizeof line, "      const float t = spec_box<FAST>(lp + %u, x0, y0, z0, tiny); %s\n"
-                              "      spec_cache_restart(cache, %uu, v%d, kk, t, rbud); v%d = %st%s;\n", off, counted, (unsigned)i, a, w, apply_open, apply_close);
-                r += line;
-            }
-        }
-        r += "    }\n";
-    };
-    // the same member in a cached evaluation: no test; a lane whose restart is this leaf starts its accumulator here
-    auto cached_member = [&](size_t i, int a, int w) {
-        const RmLeafUse use = rm_leaf_use(rec, i);
-        const uint32_t kind = RM_OP_KIND(rec[i].op);
         const unsigned off = (unsigned)i * 8u;
-        char applied[160];
-        if (use.k_rec >= 0) std::snprintf(applied, sizeof applied, "spec_smooth_union(lp + %u, v%d, t, live)", (unsigned)use.k_rec * 8u, a);
-        else std::snprintf(applied, sizeof applied, "vmin(v%d, t)", a);
-        std::snprintf(line, sizeof line, "      { const float t = %s<FAST>(lp + %u, x0, y0, z0, tiny); %sv%d = jstar == %uu ? t : %s; }\n",
-                      kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, counted, w, (unsigned)i, applied);
-        c += line;
-    };
-    int nv = 0, acc = -1;
-    for (size_t ui = 0; ui < units.size(); ui++) {
-        const BlendUnit& u = units[ui];
-        const unsigned long long bit = 1ull << ui;
-        const unsigned off = (unsigned)u.first * 8u;
-        const uint32_t kind = RM_OP_KIND(rec[(size_t)u.first].op);
-        if (u.kind == BU_START) {
-            const char* fn = kind == RM_KIND_SPHERE ? "spec_sphere<FAST>" : kind == RM_KIND_BOX ? "spec_box<FAST>" : "spec_cylinder<FAST>";
-            acc = nv++;
-            std::snprintf(line, sizeof line, "    const float v%d = %s(lp + %u, x0, y0, z0, tiny); %s\n", acc, fn, off, counted);
-            r += line;
-            std::snprintf(line, sizeof line, "    float v%d = __uint_as_float(0x7F800000u);\n    if (!(skip & 0x%llxull)) { v%d = %s(lp + %u, x0, y0, z0, tiny); %s}\n",
-                          acc, bit, acc, fn, off, counted);
-            c += line;
-        } else if (u.kind == BU_SINGLE) {
-            const int w = nv++;
-            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, acc);
-            r += line;
-            refresh_member((size_t)u.first, acc, w, true, bit);
-            std::snprintf(line, sizeof line, "    float v%d = v%d;\n    if (!(skip & 0x%llxull))\n", w, acc, bit);
-            c += line;
-            cached_member((size_t)u.first, acc, w);
-            acc = w;
-            barrier(r); barrier(c);
-        } else if (u.kind == BU_PAIR) {
-            const int g = pair_index[u.first];
-            const int w1 = nv++, w2 = nv++;
-            std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n    { const float rhs = (v%d + m) + kr%d;\n    if (spec_local_near(live, pa%d, rhs)) {\n",
-                          w1, acc, w2, acc, acc, g, g);
-            r += line;
-            refresh_member((size_t)u.first, acc, w1, leaf_tests == 1, 0ull);
-            std::snprintf(line, sizeof line, "    v%d = v%d;\n", w2, w1);
-            r += line;
-            refresh_member((size_t)u.second, w1, w2, leaf_tests == 1, 0ull);
-            std::snprintf(line, sizeof line, "    } else spec_cache_far(cache, live, 0x%llxull, (sqrt_lo(pa%d) - rhs) * 0.5f); }\n", bit, g);
-            r += line;
-            std::snprintf(line, sizeof line, "    float v%d = v%d, v%d = v%d;\n    if (!(skip & 0x%llxull)) {\n", w1, acc, w2, acc, bit);
-            c += line;
-            cached_member((size_t)u.first, acc, w1);
-            cached_member((size_t)u.second, w1, w2);
-            c += "    }\n";
-            acc = w2;
-            barrier(r); barrier(r); barrier(c); barrier(c);
-        } else if (u.kind == BU_SUB) {
-            // max(acc, -v) = acc while v + acc >= 0: outside the leaf (v > 0) with acc >= 0 is what the test establishes; the
-            // slack of that is the smaller of the two
-            const int w = nv++;
-            std::snprintf(line, sizeof line, "    float v%d = v%d;\n", w, acc);
-            r += line;
+        if (with_smooth) {
+            std::vector<std::string> lv;
+            for (int t = 0; t < T; t++) lv.push_back(leaf_expr(i, c, t));
+            emit_smooth("", w, (unsigned)u.k_rec * 8u, names(a), lv, "        ");
+        } else if (eff_mode == RM_MODE_SUB && sub_tests && (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX)) {
+            // A SUBTRACTED leaf changes max(acc, -v) only where -v > acc: at a position outside it (v > 0) with acc >= 0 -- a ray
+            // that is not inside anything -- never.  A test on values at hand (the squared distance, the accumulator), exact
+            // without any Lipschitz argument; the leaf's square root is taken only if some live lane fails it.
             if (kind == RM_KIND_SPHERE)
-                std::snprintf(line, sizeof line,
-                              "    { const float a = spec_sphere_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_sub_sphere_near(live, lp + %u, a, v%d)) { v%d = vmax_negb(v%d, spec_sphere_v<FAST>(lp + %u, a, tiny)); %s}\n"
-                              "      else spec_cache_far(cache, live, 0x%llxull, fmin_(sqrt_lo(a) - lp[%u], v%d) - m); }\n",
-                              off, off, acc, w, acc, off, counted, bit, off + 4u, acc);
+                std::snprintf(line, sizeof line, "        const float a = spec_sphere_a(lp + %u, %s);\n        if (spec_sub_sphere_near(live, lp + %u, a, %s)) %s = vmax_negb(%s, spec_sphere_v<FAST>(lp + %u, a, tiny));\n",
+                              off, P(c, 0).c_str(), off, V(a, 0).c_str(), V(w, 0).c_str(), V(a, 0).c_str(), off);
             else
-                std::snprintf(line, sizeof line,
-                              "    { const SpecBox b = spec_box_a(lp + %u, x0, y0, z0);\n"
-                              "      if (spec_sub_box_near(live, b.a, v%d)) { v%d = vmax_negb(v%d, spec_box_v<FAST>(b, tiny)); %s}\n"
-                              "      else spec_cache_far(cache, live, 0x%llxull, fmin_(sqrt_lo(b.a), v%d) - m); }\n",
-                              off, acc, w, acc, counted, bit, acc);
-            r += line;
-            std::snprintf(line, sizeof line, "    float v%d = v%d;\n    if (!(skip & 0x%llxull)) { v%d = vmax_negb(v%d, %s<FAST>(lp + %u, x0, y0, z0, tiny)); %s}\n",
-                          w, acc, bit, w, acc, kind == RM_KIND_SPHERE ? "spec_sphere" : "spec_box", off, counted);
-            c += line;
-            acc = w;
-            barrier(r); barrier(c);
-        } else {  // BU_GENERIC: evaluated as it stands; skipped in a cached evaluation only when it is dead (in front of every restart)
-            char pfx[32], accname[32];
-            std::snprintf(pfx, sizeof pfx, "g%d_", (int)ui);
-            std::snprintf(accname, sizeof accname, "v%d", acc);
-            const int w = nv++;
-            for (int which = 0; which < 2; which++) {
-                std::string& s = which ? c : r;
-                std::vector<std::string> st;
-                st.push_back(accname);
-                std::snprintf(line, sizeof line, which ? "    float v%d = v%d;\n    if (!(skip & 0x%llxull)) {\n" : "    float v%d = v%d;\n    {\n", w, acc, bit);
-                s += line;
-                if (!emit_plain_records(rec, u.first, u.last, st, pfx, counted, s) || st.size() != 1) return false;
-                std::snprintf(line, sizeof line, "    v%d = %s;\n    }\n", w, st.back().c_str());
+                std::snprintf(line, sizeof line, "        const SpecBox b = spec_box_a(lp + %u, %s);\n        if (spec_sub_box_near(live, b.a, %s)) %s = vmax_negb(%s, spec_box_v<FAST>(b, tiny));\n",
+                              off, P(c, 0).c_str(), V(a, 0).c_str(), V(w, 0).c_str(), V(a, 0).c_str());
+            s += line;
+        } else {
+            const char* op = op_name(eff_mode);
+            if (eff_mode != RM_MODE_PUSH && !op) return false;
+            for (int t = 0; t < T; t++) {
+                if (eff_mode == RM_MODE_PUSH) std::snprintf(line, sizeof line, "        %s = %s;\n", V(w, t).c_str(), leaf_expr(i, c, t).c_str());
+                else std::snprintf(line, sizeof line, "        %s = %s(%s, %s);\n", V(w, t).c_str(), op, V(a, t).c_str(), leaf_expr(i, c, t).c_str());
                 s += line;
             }
-            acc = w;
-            barrier(r); barrier(c);
         }
+        s += "    }\n";
+        stack.push_back(w);
+        after_leaf(false);
+        i = (size_t)u.last + 1u;
     }
-    // units in front of every live lane's restart are dead (one comparison each, in order, until one is alive)
-    r += "    cache.budget = fmin_(cache.budget, rbud);\n";
-    std::string tail;
-    int opened = 0;
-    for (size_t ui = 0; ui + 1 < units.size(); ui++) {  // the last unit holds the last possible restart: never dead
-        std::snprintf(line, sizeof line, "    if ((__builtin_amdgcn_ballot_w64(cache.jstar <= %uu) & live) == 0ull) { cache.skip |= 0x%llxull;\n", (unsigned)units[ui].last, 1ull << ui);
-        tail += line;
-        opened++;
+    if (stack.empty()) return false;
+    if (T == 1) {
+        std::snprintf(line, sizeof line, "    return %s;\n}\n}  // namespace rmk\n", V(stack.back(), 0).c_str());
+        s += line;
+    } else {
+        for (int t = 0; t < 4; t++) {
+            std::snprintf(line, sizeof line, "    f[%d] = %s;\n", t, V(stack.back(), t).c_str());
+            s += line;
+        }
+        s += "}\n}  // namespace rmk\n";
     }
-    for (int k = 0; k < opened; k++) tail += "}";
-    r += tail + "\n";
-    std::snprintf(line, sizeof line, "    return v%d;\n}\n", acc);
-    r += line;
-    c += line;
-    // map_scene_spec (one-position taps, should the four-tap function not be generated): the refresh without its book-keeping
-    r += "template <bool FAST>\nRM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval) {\n"
-         "    SpecCache unused;\n    return map_scene_refresh<FAST>(lp, qx, qy, qz, thr, live, tiny, n_eval, unused);\n}\n}  // namespace rmk\n";
-    c += "}  // namespace rmk\n";
-    *out = r + c;
+    *out = std::move(s);
     return true;
 }
 
@@ -1242,23 +528,18 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
     return smooth && depth <= 1;
 }
 
-// prune: 0 every leaf is evaluated, 1 far-primitive pruning on a threshold (lattice programs: rm_kernel_v5.h "Pruning"), 2 the
-// local skipping rule of programs that blend (rm_groups.h)
-enum : int { PRUNE_NONE = 0, PRUNE_LATTICE = 1, PRUNE_BLEND = 2 };
 inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune_kind, std::string* out,
                             bool* walk_generated = nullptr) {
     const bool materials = !mrec.empty();
-    const bool prune = prune_kind == PRUNE_LATTICE, blend = prune_kind == PRUNE_BLEND;
     std::string body, taps, walk;
-    // programs that blend: skip sets carried along the ray where the top level is a chain (generate_blend_cached), else the
-    // local rule tested at every evaluation
-    const bool cached = blend && jit_knob("RM_JIT_CACHED", 0) != 0 && generate_blend_cached(rec, &body);  // measured slower: off
-    if (!cached && !(blend ? generate_map_scene_blend(rec, &body) : generate_map_scene(rec, prune, &body))) return false;
+    if (!generate_scene_code(rec, prune_kind, 1, &body)) return false;
     const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
     if (walk_generated) *walk_generated = walk_spec;
     const char* taps_knob = std::getenv("RM_JIT_TAPS4");  // A/B: RM_JIT_TAPS4=0 keeps the taps on map_scene_spec
-    const bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0) &&
-                       (blend ? generate_map_scene_taps_blend(rec, &taps) : generate_map_scene_taps(rec, prune, &taps));
+    // (RM_JIT_TAPS4_SMOOTH=0: programs with a SmoothUnion keep the one-position taps)
+    bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0);
+    if (taps4 && rm_has_blend(rec) && jit_knob("RM_JIT_TAPS4_SMOOTH", 1) == 0) taps4 = false;
+    taps4 = taps4 && generate_scene_code(rec, prune_kind, 4, &taps);
     std::string s;
     // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
     s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
@@ -1266,10 +547,8 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
          "#define uint8_t rm_rtc_u8\n#define uint16_t rm_rtc_u16\n#define uint32_t rm_rtc_u32\n#define uint64_t rm_rtc_u64\n"
          "#define int32_t rm_rtc_i32\n#define int64_t rm_rtc_i64\n";
     s += "#define RM_JIT_TU 1\n";
-    if (prune) s += "#define RM_JIT_PRUNE_ON 1\n";
-    if (blend) s += "#define RM_JIT_BLEND_PRUNE 1\n";
-    if (cached) s += "#define RM_JIT_CACHED 1\n";
-    if (cached && jit_knob("RM_JIT_PRUNE_STATS", 0) == 5) s += "#define RM_JIT_COUNT_REFRESH 1\n";
+    if (prune_kind == PRUNE_LATTICE) s += "#define RM_JIT_PRUNE_ON 1\n";
+    if (prune_kind == PRUNE_BLEND) s += "#define RM_JIT_BLEND_PRUNE 1\n";
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
     if (structure_allows_bound_walk(rec)) s += "#define RM_JIT_BOUND_WALK 1\n";
@@ -1321,8 +600,23 @@ inline const char* const* compile_options(int* n) {
 }
 // Where the code object of `src` lives in the disk cache ("" when the cache is off): keyed by everything that
 // determines it -- the generated source, the embedded headers, the compile options, the compiler (file + version).
+// Directory of the disk cache: RM_JIT_CACHE_DIR if set ("" or "off" switches the cache off), else `jit_cache` next to this library
+// (created on first use; a directory that cannot be written simply leaves the cache cold).  The interactive host this replaces
+// (an editor whose every structural edit is a new program) pays the compiler once per structure EVER, not once per process:
+// the analogue of a driver's on-disk shader cache.  build() warms it for the structures of the BASELINE scenes.
+inline std::string cache_dir() {
+    if (const char* env = std::getenv("RM_JIT_CACHE_DIR")) return (env[0] == 0 || std::strcmp(env, "off") == 0) ? std::string() : std::string(env);
+    Dl_info info;
+    std::memset(&info, 0, sizeof info);
+    if (!dladdr(reinterpret_cast<void*>(&cache_dir), &info) || !info.dli_fname) return std::string();
+    std::string lib(info.dli_fname);
+    const size_t slash = lib.rfind('/');
+    if (slash == std::string::npos) return std::string();
+    return lib.substr(0, slash) + "/jit_cache";
+}
 inline std::string cache_path(const std::string& src) {
-    const char* dir = std::getenv("RM_JIT_CACHE_DIR");
+    const std::string dir_s = cache_dir();
+    const char* dir = dir_s.empty() ? nullptr : dir_s.c_str();
     Rtc& rtc = Rtc::get();
     if (!dir || !rtc.ok()) return std::string();
     uint64_t h = fnv1a(src.data(), src.size());
@@ -1343,7 +637,7 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
     if (from_cache) *from_cache = false;
     if (!rtc.ok()) { *log = rtc.error; return false; }
     const auto t0 = std::chrono::steady_clock::now();
-    // Optional disk cache (RM_JIT_CACHE_DIR): a second process starts warm.
+    // Disk cache (cache_dir()): a second process starts warm.
     const std::string cache_file = cache_path(src);
     if (!cache_file.empty()) {
         if (FILE* f = std::fopen(cache_file.c_str(), "rb")) {
@@ -1390,6 +684,10 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
     }
     rtc.DestroyProgram(&prog);
     if (ok && !cache_file.empty()) {  // write-then-rename: another process never sees half a file
+        {
+            const size_t slash = cache_file.rfind('/');
+            if (slash != std::string::npos && slash > 0) (void)::mkdir(cache_file.substr(0, slash).c_str(), 0777);  // (exists already: fine)
+        }
         const std::string tmp = cache_file + ".part" + std::to_string((long)getpid());
         if (FILE* f = std::fopen(tmp.c_str(), "wb")) {
             CacheHeader hd;
@@ -1423,6 +721,7 @@ struct Entry {
     std::string log;
     double compile_ms = 0.0;
     bool material_walk = false;  // the kernel carries the generated material walk (it needs no LDS stack for the material phase)
+    bool from_cache = false;     // the code object was read from the disk cache (compile_ms is then the time of that read)
     std::string cached_source;  // non-empty iff `code` came from the disk cache: if the loader rejects it, the file is
                                 // dropped and this source compiled afresh, once (rm_abi.hip specialised_kernel)
     // Filled by the caller's (HIP) thread under `m`: device ordinal -> {hipModule_t, hipFunction_t}.
@@ -1460,7 +759,7 @@ public:
     std::shared_ptr<Entry> request(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune) {
         // a tagged program's kernel also depends on where its tags sit (the material walk is generated from mrec), and on the
         // A/B knobs of the generator as the environment holds them now (so that a process may compare two settings)
-        static const char* const knobs[] = {"RM_JIT_BLEND_LEAF_TESTS", "RM_JIT_BLEND_UPFRONT", "RM_JIT_CACHED", "RM_JIT_CACHED_MIN_UNITS", "RM_JIT_GUARD_FENCE", "RM_JIT_LEAF_TESTS", "RM_JIT_MATERIAL_WALK",
+        static const char* const knobs[] = {"RM_JIT_GUARD_FENCE", "RM_JIT_MATERIAL_WALK",
                                             "RM_JIT_PRIO_LONG_RAYS", "RM_JIT_PRUNE_STATS", "RM_JIT_SCHED_BARRIER", "RM_JIT_SCHED_BARRIER_TAPS",
                                             "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU"};
         std::string knob_key;
@@ -1527,6 +826,7 @@ private:
             const bool ok = compile(job.source, &code, &log, &ms, &from_cache);
             {
                 std::lock_guard<std::mutex> g(job.entry->m);
+                job.entry->from_cache = ok && from_cache;
                 if (ok && from_cache) job.entry->cached_source = std::move(job.source);
                 job.entry->code = std::move(code);
                 job.entry->log = std::move(log);

@@ -48,9 +48,10 @@ RM_DEV LdsF lds_vector_base(const void* generic_lds_ptr) {
     asm("v_mov_b32 %0, %1" : "=v"(v) : "s"(s));
     return (LdsF)(__SIZE_TYPE__)v;  // LDS pointers are 32 bits wide; the widening only silences the host pass
 }
-// `live`: wave mask of the lanes whose value will be used (far tests ignore the others)
+// `need`: the units of the program (rm_units.h) some live lane may depend on, one bit each, from wave_cull_* below (all ones
+// when the kernel does not cull); `live`: wave mask of the lanes whose value will be used
 template <bool FAST>
-RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval);
+RM_DEV float map_scene_spec(LdsF lp, float qx, float qy, float qz, unsigned long long need, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval);
 #ifdef RM_JIT_MATERIAL_WALK
 // The material walk of a tagged program as straight-line code (rm_jit.h generate_material_walk): which material does the
 // surface at (x, y, z) carry.  mp: the tagged records in device memory (uniform addresses: scalar loads).
@@ -60,17 +61,17 @@ RM_DEV uint32_t map_scene_material_spec(const RmRecord* __restrict__ mp, float q
 #ifdef RM_JIT_TAPS4
 // The four normal taps of a hit at c in one pass (rm_jit.h generate_map_scene_taps): f[t] = map_scene(c + k_t eps).
 template <bool FAST>
-RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, unsigned long long live, SqrtGuard& tiny, float (&f)[4]);
+RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, unsigned long long need, unsigned long long live, SqrtGuard& tiny, float (&f)[4]);
 #endif
 
-// ---- Pruning of far primitives (specialised kernels only; exact) ------------------------------------
+// ---- Pruning of far primitives (exact) ----------------------------------------------------------------
 // A tree of min / max / negation over leaf values is monotone in every leaf: as a function of one
 // leaf's signed value t (t = v for a leaf the tree value F grows with, t = -v below an odd number of
 // subtraction right-hand sides) it is  F(t) = max(lo, min(hi, t))  for some lo <= hi, or constant.
 // Hence, if F is known to lie in [-thr, thr] and a leaf has v > thr, then t > thr >= F(t) forces
 // hi < t (resp. t < -thr <= F(t) forces lo > t): F does not depend on that leaf any more and is
 // unchanged -- bit for bit, min and max only select -- if the leaf value is replaced by +inf.  The
-// generated code then skips the leaf's square root: "acc = min(acc, +inf)" and "acc = max(acc, -inf)"
+// generated code then skips the leaf: "acc = min(acc, +inf)" and "acc = max(acc, -inf)"
 // leave acc alone; a leaf that is pushed becomes the constant +inf.
 //
 // thr comes from the previous evaluation of the same ray.  Every node type admitted here (sphere,
@@ -82,62 +83,190 @@ RM_DEV void map_scene_taps(LdsF lp, float cx, float cy, float cz, float thr, uns
 //   first evaluation of a ray                                 -> thr = +inf (nothing is skipped)
 // m = 4e-6 (scene_scale + |ro|_1 + |q'|_1) covers 3E (E <= 4e-7 of that scale: a handful of binary32
 // roundings of quantities no larger than it) plus the rounding of q' itself, with 3x to spare.
-// The skip itself is a wave-uniform branch: a primitive is evaluated if ANY live lane needs it.
-//   sphere: v = sqrt(a) - r > thr  <=  a > ((thr + r) k)^2         k = 1.000005 (r k: RmRecord::p[4])
-//   box:    a = |max(q,0)|^2 > thr^2 k^2 implies a > 0, so the inner term is +0 and v = sqrt(a) > thr
-// NaN or inf anywhere (parameters, position, thr) makes the comparison false: the primitive is evaluated.
-// Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned.
+// Programs with a Plane (|n| arbitrary) or a SmoothUnion (not a lattice operator) are not pruned this way; programs that
+// blend have rules of their own (below).
 constexpr float kPruneAbs = 4.0e-6f;
 // The thresholds are kept (a register per ray, |sd| of a hit in its hit-buffer entry) by the generated kernels compiled
-// with pruning and by the library's interpreter kernels, whose chain loop prunes too (rm_interp.h map_scene_chain_pruned)
-#if defined(RM_JIT_PRUNE_ON) || defined(RM_JIT_CACHED) || !defined(RM_JIT_TU)
+// with pruning and by the library's interpreter kernels
+#if defined(RM_JIT_PRUNE_ON) || !defined(RM_JIT_TU)
 #define RM_PRUNE_PLUMBING 1
 #endif
-// "is the leaf near for ANY live lane": the wave mask of the comparison itself (one v_cmp writing a scalar pair),
-// combined with the live mask on the scalar side.  Written as __ballot(live && !far) the predicate is not a comparison
-// any more and the compiler materialises it in a VGPR and compares it back (v_cndmask + v_cmp_ne: two vector
-// instructions per far test, ~9 % of the march kernel's).
-RM_DEV bool spec_any_near(unsigned long long live, bool far) { return (__builtin_amdgcn_ballot_w64(!far) & live) != 0ull; }
 
+// ---- Wave-level culling: WHICH units does this wave have to evaluate ----------------------------------------------------
+// Rounds 1 and 2 tested every pair of leaves (and every box) against every lane's own threshold, 64 lanes wide, at every
+// evaluation: ~120 of the ~330 vector instructions of a march step of the metric scene.  But the 64 rays of a wave come
+// from one 8x8-pixel tile and march in step: their positions lie in a small ball.  So the test is TRANSPOSED -- lane u
+// looks at unit u (rm_units.h; its bounded stand-in sits in LDS behind the program, RmDecoded::units) and decides for the
+// whole wave:
+//   p*   the position of the first live lane,  rho >= max over live lanes |p_l - p*|   (one wave reduction)
+//   unit u with centre c, outer radius R, inner radius r_in:  for every live lane
+//        L_u = |p* - c| - R - rho  <=  value_u(p_l)  <=  |p* - c| + rho - r_in = H_u      (triangle inequality)
+// LATTICE programs (threshold rule above): T >= max over live lanes thr_l (a second reduction); unit u is needed unless
+//   L_u > T.  A CPU simulation of the metric frame (tools/sim/wave_cull_sim.py) has this evaluate 4.5 of 16 leaves per
+//   step where the per-lane pair tests evaluate 5.5 and a per-lane, per-leaf test 4.2.
+// Programs that BLEND, top-level chain (rm_units.h).  With a_hi(u) = min over the Union / SmoothUnion units j < u of H_j
+//   (the accumulator a unit meets is at most the smallest leaf blended in so far) and a_lo(u) = min_j L_j - kmax (a chain
+//   of blends never falls more than the largest k below its smallest leaf: rm_decode.h [*]; Subtraction and Intersection
+//   only raise it) -- two prefix minima over the lanes --:
+//        Union / SmoothUnion(k)   L_u >= a_hi + k + m   -> the operator returns the accumulator (h = 0): skipped
+//                                 H_u <= a_lo - k - m   -> it returns the leaf: RESTART, every unit in front of u is dead
+//        Subtraction              L_u + a_lo >= m       -> max(acc, -v) = acc: skipped
+//        Intersection             H_u <= a_lo - m       -> max(acc, v) = acc: skipped
+//   a_hi is only an upper bound while no Subtraction / Intersection has raised the accumulator: the first one that is not
+//   skipped (and any opaque unit, behind which nothing is known) POISONS the rules -- every unit behind it is evaluated.
+//   Same simulation, config 3: 4.4 of 16 units per step against 7.2 for the per-lane rule of the first half of this round.
+// All comparisons fail on a NaN (the unit is evaluated); m is the margin of the threshold rule at p*, with rho added.
+// Cost: ~50 vector instructions per evaluation for a lattice program, ~100 for a blending one, whatever the number of units.
+#define RM_DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), 0xF, 0xF, false))
+// largest value over the wave, wave-uniform (all 64 lanes must be active; lanes without a value pass 0).  Four DPP steps
+// leave every row of 16 lanes with its maximum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+RM_DEV uint32_t wave_max_u32(uint32_t v) {
+    uint32_t t;
+    t = RM_DPP(0u, v, 0xB1); v = t > v ? t : v;
+    t = RM_DPP(0u, v, 0x4E); v = t > v ? t : v;
+    t = RM_DPP(0u, v, 0x141); v = t > v ? t : v;
+    t = RM_DPP(0u, v, 0x140); v = t > v ? t : v;
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
+}
+// minimum over the lanes BELOW this one (+inf for lane 0); all 64 lanes active.  row_shr:1,2,3, row_shr:4, row_shr:8 scan a row
+// of 16, row_bcast:15 and row_bcast:31 carry the rows' totals on (a lane without a source keeps +inf; min is idempotent, so
+// it does not matter that a total may be counted twice); then one shift by a lane.
+RM_DEV float wave_exclusive_min(float x) {
+    const uint32_t inf = 0x7F800000u, v = __float_as_uint(x);
+    float s = fmin_(x, __uint_as_float(RM_DPP(inf, v, 0x111)));
+    s = fmin_(s, __uint_as_float(RM_DPP(inf, v, 0x112)));
+    s = fmin_(s, __uint_as_float(RM_DPP(inf, v, 0x113)));
+    s = fmin_(s, __uint_as_float(RM_DPP(inf, __float_as_uint(s), 0x114)));
+    s = fmin_(s, __uint_as_float(RM_DPP(inf, __float_as_uint(s), 0x118)));
+    s = fmin_(s, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(s), 0x142, 0xA, 0xF, false)));
+    s = fmin_(s, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(s), 0x143, 0xC, 0xF, false)));
+    const float up = __shfl_up(s, 1, 64);
+    return (threadIdx.x & 63u) == 0u ? __uint_as_float(inf) : up;
+}
+struct WaveBall {  // wave-uniform: the live lanes' positions lie within rho of (px, py, pz)
+    float px, py, pz, rho;
+};
+RM_DEV WaveBall wave_ball(float x, float y, float z, bool is_live, unsigned long long live_m) {
+    WaveBall b;
+    const int first = __builtin_ctzll(live_m);  // (the caller has a live lane)
+    b.px = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), first));
+    b.py = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), first));
+    b.pz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(z), first));
+    const float dx = x - b.px, dy = y - b.py, dz = z - b.pz;
+    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    // (non-negative floats order like their bit patterns; a NaN's pattern is above +inf's and wins: rho = NaN, nothing is far)
+    const float r2 = __uint_as_float(wave_max_u32(is_live ? __float_as_uint(d2) : 0u));
+    b.rho = __builtin_amdgcn_sqrtf(r2) * 1.00001f + 1.0e-30f;
+    return b;
+}
+// The unit table in LDS, one ROW per field so that lane u's reads do not collide with its neighbours' (unit records are 32
+// bytes apart in device memory; a workgroup transposes them when it stages the program): row f of n_units floats holds
+// RmDecoded::units[u].p[f] -- 0..2 centre, 3 outer radius, 4 inner radius, 5 blend radius, 6 kind.
+constexpr uint32_t kUnitRows = 7u;
+RM_DEV void stage_units(uint32_t* lunits, const RmRecord* __restrict__ units, uint32_t n_units, uint32_t tid, uint32_t n_threads) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(units);
+    for (uint32_t k = tid; k < kUnitRows * n_units; k += n_threads) {
+        const uint32_t f = k / n_units, u = k - f * n_units;
+        lunits[k] = src[8u * u + 1u + f];
+    }
+}
+struct UnitBounds { float L, H, k; uint32_t kind; };
+RM_DEV UnitBounds unit_bounds(const uint32_t* lunits, uint32_t n_units, const WaveBall& b) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const float* u = reinterpret_cast<const float*>(lunits) + (lane < n_units ? lane : 0u);
+    const float dx = u[0] - b.px, dy = u[n_units] - b.py, dz = u[2u * n_units] - b.pz;
+    const float d = __builtin_amdgcn_sqrtf(__builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx)));
+    UnitBounds r;
+    r.L = (d * 0.999998f - u[3u * n_units]) - b.rho;  // v_sqrt_f32 is within an ulp, the fused sum of squares within 3e-7
+    r.H = (d * 1.000002f + b.rho) - u[4u * n_units];
+    r.k = u[5u * n_units];
+    r.kind = __float_as_uint(u[6u * n_units]);
+    return r;
+}
+// (Measured and dropped: a mask good for TWO march steps -- a step moves a ray by at most thr and the next threshold is at most
+// 2.0001 thr + m', so "|p* - c| - R - (rho + T) > 2.0001 T + m'" holds at both -- halves the cost of the masks and nearly
+// doubles the leaves evaluated, 3.6 -> 6.8 of 16 per step on the metric scene: march kernel 0.544 -> 0.613 ms,
+// profiles/r03_wave_level_culling_ab.txt.)
+RM_DEV unsigned long long wave_cull_lattice(const uint32_t* lunits, uint32_t n_units, float x, float y, float z, float thr, bool is_live,
+                                            unsigned long long live_m) {
+    const unsigned long long valid = n_units >= 64u ? ~0ull : ((1ull << n_units) - 1ull);
+    const WaveBall b = wave_ball(x, y, z, is_live, live_m);
+    const float T = __uint_as_float(wave_max_u32(is_live ? __float_as_uint(thr) : 0u)) * 1.000005f;  // thr >= 0 or NaN (wins)
+    // far: |p* - c| - R - rho > T, decided on the squares (every term is >= 0; a NaN or an infinity makes it false)
+    const uint32_t lane = threadIdx.x & 63u;
+    const float* u = reinterpret_cast<const float*>(lunits) + (lane < n_units ? lane : 0u);
+    const float dx = u[0] - b.px, dy = u[n_units] - b.py, dz = u[2u * n_units] - b.pz;
+    const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+    const float s = (T + b.rho) + u[3u * n_units];
+    return ~__builtin_amdgcn_ballot_w64(d2 > (s * s) * 1.000004f) & valid;
+}
+// margin_scale: scene_scale + |ro|_1 (the `prune_scale` of the kernels)
+RM_DEV unsigned long long wave_cull_blend(const uint32_t* lunits, uint32_t n_units, float kmax, float x, float y, float z, float extra_margin,
+                                          float margin_scale, bool is_live, unsigned long long live_m) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const unsigned long long valid = n_units >= 64u ? ~0ull : ((1ull << n_units) - 1ull);
+    const WaveBall b = wave_ball(x, y, z, is_live, live_m);
+    const float m = kPruneAbs * (margin_scale + ((__builtin_fabsf(b.px) + __builtin_fabsf(b.py)) + __builtin_fabsf(b.pz)) + 2.0f * b.rho) + extra_margin;
+    const UnitBounds u = unit_bounds(lunits, n_units, b);
+    const bool in_range = lane < n_units;
+    const float inf = __uint_as_float(0x7F800000u);
+    const bool blends = in_range && (u.kind == RM_UNIT_UM || u.kind == RM_UNIT_START);
+    const float a_hi = wave_exclusive_min(blends ? u.H : inf);
+    const float a_lo = wave_exclusive_min(blends ? u.L : inf) - kmax;
+    const bool is_um = u.kind == RM_UNIT_UM, is_sub = u.kind == RM_UNIT_SUB, is_int = u.kind == RM_UNIT_INTER;
+    const bool skip = (is_um && u.L >= (a_hi + u.k) + m) || (is_sub && u.L + a_lo >= m) || (is_int && u.H <= a_lo - m);
+    const bool restart = is_um && u.H <= (a_lo - u.k) - m;
+    const unsigned long long opaque_m = __builtin_amdgcn_ballot_w64(u.kind == RM_UNIT_OPAQUE) & valid;
+    const unsigned long long before_opaque = opaque_m ? ((1ull << __builtin_ctzll(opaque_m)) - 1ull) : ~0ull;
+    const unsigned long long restart_m = __builtin_amdgcn_ballot_w64(restart) & valid & before_opaque;
+    const unsigned long long skip_m = __builtin_amdgcn_ballot_w64(skip) & valid & before_opaque;
+    const uint32_t r = restart_m ? 63u - (uint32_t)__builtin_clzll(restart_m) : 0u;
+    const unsigned long long from_r = ~((1ull << r) - 1ull);  // units r .. 63
+    // the first unit at or behind the restart that may have raised the accumulator, or behind which nothing is known
+    const unsigned long long poison_m = (opaque_m | (__builtin_amdgcn_ballot_w64((is_sub || is_int) && !skip) & valid)) & from_r;
+    const unsigned long long behind_poison = poison_m ? ~((2ull << __builtin_ctzll(poison_m)) - 1ull) : 0ull;  // (2 << 63 = 0: none)
+    return valid & from_r & (~skip_m | behind_poison | (1ull << r));
+}
+#undef RM_DPP
+
+#if !defined(RM_JIT_TU)  // diagnostics (rm_selftest_wave)
+__global__ __launch_bounds__(64) void rm_selftest_wave_kernel(const float* in, float* out, uint32_t n_waves) {
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    const float x = in[i];
+    out[i] = __uint_as_float(wave_max_u32(__float_as_uint(x)));
+    out[64u * n_waves + i] = wave_exclusive_min(x);
+}
+#endif
+
+// Is unit u (a compile-time constant in generated code) in the wave's mask.  The mask goes through an empty asm at every use:
+// left alone the compiler computes all the tests where the mask is born and keeps sixteen 64-bit lane masks alive across the
+// whole evaluation -- 30 more scalar registers spilled, which costs the vector register that decides between 6 and 5 waves
+// per SIMD.  With the asm each test is born where it is used: s_bitcmp1_b64 + s_cbranch_scc.
+RM_DEV bool unit_needed(unsigned long long need, uint32_t u) {
+    asm volatile("" : "+s"(need));
+    return ((need >> u) & 1ull) != 0ull;
+}
+
+typedef float lds_f4 __attribute__((ext_vector_type(4)));
+typedef float lds_f2 __attribute__((ext_vector_type(2)));
+RM_DEV lds_f4 lds_load4(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f4*>(r); }
+RM_DEV lds_f2 lds_load2(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f2*>(r); }
 // Parameter reads of the generated code.  A specialised kernel stages every record ROTATED by one dword -- p[0..6] at
 // dwords 0..6, the opcode (which generated code never reads) at dword 7 -- so that the parameters of a record start on
 // a 32-byte boundary and are fetched with ONE ds_read_b128 (+ a ds_read_b64 for a box) instead of two or three
 // ds_read2_b32: the LDS pipe of a CU serves a wave64 b32 / b64 read in 2 cycles and a read2_b32 / b128 in 4
 // (MI355X_MICROARCH.md, LDS), it is shared by the four SIMDs, and at ~40 parameter reads per evaluation it was ~60 %
 // busy (SQ_ACTIVE_INST_LDS) next to a vector unit at ~80 %.
-typedef float lds_f4 __attribute__((ext_vector_type(4)));
-typedef float lds_f2 __attribute__((ext_vector_type(2)));
-RM_DEV lds_f4 lds_load4(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f4*>(r); }
-RM_DEV lds_f2 lds_load2(LdsF r) { return *reinterpret_cast<const __attribute__((address_space(3))) lds_f2*>(r); }
-
 RM_DEV float spec_sphere_a(LdsF r, float qx, float qy, float qz) {
     const lds_f4 p = lds_load4(r);  // cx cy cz r
     const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
     return (dx * dx + dy * dy) + dz * dz;  // the argument of sdf_sphere_t's sqrt, same operations
 }
-RM_DEV bool spec_sphere_far(LdsF r, float a, float thrk) {
-    const float t = thrk + r[4];
-    return a > t * t;
-}
 template <bool FAST>
 RM_DEV float spec_sphere_v(LdsF r, float a, SqrtGuard& tiny) { return sqrt_sel<FAST>(a, tiny) - r[3]; }
-// Grouped far test (RmDecoded::groups): centre and pre-multiplied radius of the pair's bounding sphere in one 16-byte
-// read.  The squared distance is a bound here, not a value of the arithmetic contract, so it may use fused multiply-adds
-// (their rounding error is no larger than the unfused form's, which the factor 1.000005 in the radius covers).
-RM_DEV bool spec_group_near(unsigned long long live, LdsF r, float qx, float qy, float qz, float thrk) {
-    const lds_f4 p = lds_load4(r);  // cx cy cz R' * 1.000005
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float t = thrk + p.w;
-    return spec_any_near(live, a > t * t);
-}
-RM_DEV uint32_t spec_group_near_lanes(unsigned long long live, LdsF r, float qx, float qy, float qz, float thrk) {  // diagnostics
-    const lds_f4 p = lds_load4(r);
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    const float a = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float t = thrk + p.w;
-    return (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(!(a > t * t)) & live);
-}
 // Subtracted leaves (mode SUB fused into the leaf): max(acc, -v) = acc whenever -v <= acc, in particular at every position
 // OUTSIDE the leaf (v > 0) while acc >= 0.  Sphere: a > (r k)^2 (r k: RmRecord::p[4], k = 1.000005) puts sqrt(a) above r by
 // more than its rounding, so the computed v = sqrt(a) - r is > 0; NaN fails the comparison and the leaf is evaluated.
@@ -149,108 +278,6 @@ RM_DEV bool spec_sub_sphere_near(unsigned long long live, LdsF r, float a, float
 RM_DEV bool spec_sub_box_near(unsigned long long live, float a, float acc) {
     return ((__builtin_amdgcn_ballot_w64(!(a > 0.0f)) | __builtin_amdgcn_ballot_w64(!(acc >= 0.0f))) & live) != 0ull;
 }
-// ---- The LOCAL skipping rule (programs that blend with SmoothUnion; rm_groups.h) ---------------------------------
-// smin_k(acc, v) and min(acc, v) return acc, bit for bit, when v >= acc + k (k = 0 for a Union): h = 0 and
-// min(acc, v) - 0 = acc (spec_smooth_union / exec_command RM_MODE_SMOOTH).  No bound on the scene value is involved and no
-// Lipschitz argument: the test compares a LOWER BOUND of the leaf value at this very position -- sqrt(a) - R, a the squared
-// distance to a bounding sphere of the leaf or of a pair of leaves -- with the accumulator the leaf is about to be blended
-// into.  rhs = (acc + m) + (k + R): the leaf (pair) is skipped when sqrt(a) > rhs for EVERY live lane, i.e. rhs < 0 or
-// a > rhs^2.  m = 4e-6 (scene_scale + |ro|_1 + |q|_1), the margin of "Pruning" above: it covers the leaf's own evaluation
-// error (<= 4e-7 of that scale), the roundings of a, rhs and rhs^2 (<= 2e-7 of sqrt(a) <= |q|_1 + scene_scale each) and the
-// strictness v > acc that the selection by min needs; scene_scale includes the blend radii (rm_decode.h).
-// NaN: an accumulator that is NaN makes both comparisons false (the leaf is evaluated: smin(NaN, v) = v); a NaN position
-// or leaf can only make the leaf value NaN, which smin and min ignore (fmin drops it, h = max(NaN, 0) / k = 0): skipping
-// is what the evaluation would have returned.
-RM_DEV bool spec_local_near(unsigned long long live, float a, float rhs) {
-    const unsigned long long far = __builtin_amdgcn_ballot_w64(a > rhs * rhs) | __builtin_amdgcn_ballot_w64(rhs < 0.0f);
-    return (~far & live) != 0ull;
-}
-// A box's value is sqrt(a) + (inside term) with a = |max(q, 0)|^2, and the inside term is +0 only when a > 0: its lower
-// bound sqrt(a) holds only then, so there is no "rhs < 0" shortcut -- a > rhs^2 >= 0 proves both.
-RM_DEV bool spec_local_box_near(unsigned long long live, float a, float rhs) {
-    return (~__builtin_amdgcn_ballot_w64(a > rhs * rhs) & live) != 0ull;
-}
-// Squared distance to the bounding sphere of a pair (a bound: fused multiply-adds) and what the test adds to the
-// accumulator: kr = (k + R') * 1.000005 (RmDecoded::blend_prunable)
-RM_DEV float spec_pair_a(LdsF r, float qx, float qy, float qz, float& kr) {
-    const lds_f4 p = lds_load4(r);
-    const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
-    kr = p.w;
-    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-}
-// The four taps of a hit (map_scene_taps): the bound is taken at the hit position c, eps sqrt(3) from every tap (the
-// caller's margin carries it), against each tap's own accumulator; skipped only if far for all four.
-RM_DEV bool spec_local_near4(unsigned long long live, float a, const float (&rhs)[4], bool sphere_bound) {
-    unsigned long long far = ~0ull;
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-        unsigned long long f = __builtin_amdgcn_ballot_w64(a > rhs[t] * rhs[t]);
-        if (sphere_bound) f |= __builtin_amdgcn_ballot_w64(rhs[t] < 0.0f);
-        far &= f;
-    }
-    return (~far & live) != 0ull;
-}
-// the blend radius as the rule uses it: a SmoothUnion with k <= 0 is a plain min
-RM_DEV float spec_local_k(LdsF r) { return fmax_(r[0], 0.0f); }
-
-// ---- Skip sets carried ALONG a ray (generated kernels compiled with RM_JIT_CACHED) ---------------------------------------
-// Every skipping rule above decides, at one position, from quantities that are 1-Lipschitz along the ray: leaf values and
-// their lower bounds, the accumulators a chain blends them into (min, max(a, -b), max, smin_k of 1-Lipschitz operands; a
-// Plane with |n| > 1 is not, programs with a Plane are not compiled this way), the scene value behind `thr`.  A march
-// only moves a ray along its own half-line, |rd| <= 1: between the evaluation at distance sc_0 and a later one at sc_n
-// every such quantity changes by at most (sc_n - sc_0) + 2E (E: the evaluation error, inside the margin m the caller adds
-// to `thr`).  So a decision taken at sc_0 with SLACK to spare stays true while the ray has not used the slack up:
-//   REFRESH  an evaluation with all tests (map_scene_spec).  It also returns, for the wave, the set of units it skipped
-//            for every live lane -- `skip`, one bit per unit (pair, leaf, segment) --, and per lane the smallest slack of
-//            those decisions, as a distance budget;
-//   CACHED   the evaluations that follow (map_scene_cached) run no test at all: a unit is evaluated iff its bit is clear.
-//            Valid for a lane while  sc_0 + budget > sc_n + thr_n  (two vector instructions per step); when that fails
-//            for any live lane, when a lane takes a new ray, or when the rays have come so much closer to the scene that
-//            a new look would skip more (thr halved for most lanes), the next evaluation is a refresh.
-// A unit is only put in the set if its slack covers `tau`, about one more step of the ray: otherwise it is simply evaluated.
-// Programs that blend also get RESTARTS from a refresh: at a Union / SmoothUnion of the top-level chain whose leaf is at
-// least k below the accumulator (v <= acc - k: the operator returns v, bit for bit: h = 0, min(acc, v) - 0 = v), everything
-// in front of that leaf is dead for the lane; `jstar` is the record of the last such leaf, and cached evaluations start the
-// lane's accumulator there (lanes whose restart lies further on compute garbage until they reach it).
-struct SpecCache {
-    unsigned long long skip = 0ull;  // wave-uniform
-    float budget = __uint_as_float(0x7F800000u);  // per lane: how far the ray may move before some decision could change
-    uint32_t jstar = 0u;             // per lane: record index of the lane's restart leaf, 0 = none
-    float tau = __uint_as_float(0x7F800000u);     // in, per lane: slack a decision needs to be worth remembering
-};
-// a unit that was skipped for every live lane: remember it if every live lane has slack to spare (half: the accumulator
-// and the leaf may each move against the decision)
-RM_DEV void spec_cache_far(SpecCache& c, unsigned long long live, unsigned long long bit, float half_slack) {
-    if ((__builtin_amdgcn_ballot_w64(!(half_slack > c.tau)) & live) == 0ull) {
-        c.skip |= bit;
-        c.budget = fmin_(c.budget, half_slack);  // (a NaN slack fails the test above)
-    }
-}
-// an evaluated Union / SmoothUnion member of the top-level chain as a restart: the leaf value v, the accumulator it meets
-RM_DEV void spec_cache_restart(SpecCache& c, uint32_t rec, float acc, float kk, float v, float& rbud) {
-    const float half = ((acc - kk) - v) * 0.5f;
-    const bool cand = half > c.tau;  // NaN: no
-    c.jstar = cand ? rec : c.jstar;
-    rbud = cand ? half : rbud;
-}
-// lower bound of a square root (for slacks: v_sqrt_f32 is within an ulp)
-RM_DEV float sqrt_lo(float a) { return __builtin_amdgcn_sqrtf(a) * 0.999999f; }
-template <bool FAST>
-RM_DEV float map_scene_cached(LdsF lp, float qx, float qy, float qz, unsigned long long skip, uint32_t jstar, unsigned long long live,
-                              SqrtGuard& tiny, uint32_t& n_eval);
-template <bool FAST>
-RM_DEV float map_scene_refresh(LdsF lp, float qx, float qy, float qz, float thr, unsigned long long live, SqrtGuard& tiny, uint32_t& n_eval,
-                               SpecCache& cache);
-// largest value over the wave (all 64 lanes participate; lanes without a value pass 0)
-RM_DEV uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
 struct SpecBox { float qx, qy, qz, a; };
 RM_DEV SpecBox spec_box_a(LdsF r, float px, float py, float pz) {
     const lds_f4 c = lds_load4(r);       // cx cy cz rx
@@ -570,6 +597,11 @@ struct V5Work {
                             // and read by the NEXT draw's rm_tile_sort_v5 (RM_OPT_BALANCE = 3: longest tiles first)
 };
 
+// (Round 3 tried to drop the sort kernel -- the pre-pass appending every tile that needs marching to one of four lists by the
+// class of its last duration, one atomic per tile, the march kernel walking the classes: the frame's ~7 500 returning atomics
+// on four addresses took the pre-pass from 0.06 to 0.21 ms, and four classes order the tiles worse than the sort's 64 buckets
+// (8-node scene: march kernel 0.244 -> 0.277 ms).  How much the order is worth: last frame's durations 0.532 ms, pending
+// pixels 0.65, order of arrival 0.66 on the metric frame.  profiles/r03_work_list_by_atomics_negative.txt)
 // b for the lanes whose bit is set in the wave mask m, a for the others: one v_cndmask_b32 with the mask as its
 // scalar operand.
 RM_DEV float select_by_mask(float a, float b, unsigned long long m) {
@@ -642,8 +674,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float eps = 0.0001f;                                    // wgsl:136
     if (PROG_IN_LDS) {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(L.prog);
-        // program, then group records; generated code reads them rotated by one dword (parameters first: lds_load4)
-        for (uint32_t k = tid; k < (L.n_rec + L.n_grp) * 8u; k += 64u * WPT) lprog[SPEC ? ((k & ~7u) | ((k + 7u) & 7u)) : k] = src[k];
+        // program (generated code reads the records rotated by one dword: parameters first, lds_load4), then the unit table
+        for (uint32_t k = tid; k < L.n_rec * 8u; k += 64u * WPT) lprog[SPEC ? ((k & ~7u) | ((k + 7u) & 7u)) : k] = src[k];
+        stage_units(lprog + 8u * L.n_rec, L.prog + L.n_rec, L.n_grp, tid, 64u * WPT);  // (7 of a unit record's 8 dwords: it fits the same space)
     }
     if (tid == 0u) *s_veto = 0u;
     if (tid < 16u) sample_offset(u, tid >> 2, tid & 3u, s_off[2u * tid], s_off[2u * tid + 1u]);  // two divisions per sample, once
@@ -669,29 +702,65 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float bound_scale = prune_scale + L.smooth_slack;  // scale of the coordinates the bounds are computed from
     const LdsF lprog_v = lds_vector_base(lprog);  // SPEC: the program's LDS copy, base address in a VGPR (see LdsF)
     uint32_t n_eval = 0u;  // diagnostics (pruned kernels compiled with statistics): leaves actually evaluated, per wave
+    // Wave-level culling (above): the units of the program this wave has to evaluate at its live lanes' positions.  Generated
+    // kernels know at compile time whether and how they cull; the interpreter kernels look at the launch (flags bit 3).
+    const uint32_t* lunits = lprog + 8u * L.n_rec;  // the unit records behind the program (PROG_IN_LDS kernels only)
+    auto units_needed = [&](float x, float y, float z, float thr, float extra_margin, bool is_live, unsigned long long live_mask) -> unsigned long long {
+        if constexpr (SPEC) {
+#if defined(RM_JIT_PRUNE_ON)
+            return wave_cull_lattice(lunits, L.n_grp, x, y, z, thr, is_live, live_mask);
+#elif defined(RM_JIT_BLEND_PRUNE)
+            return wave_cull_blend(lunits, L.n_grp, L.unit_kmax, x, y, z, extra_margin, prune_scale, is_live, live_mask);
+#else
+            return ~0ull;
+#endif
+        } else if constexpr (PROG_IN_LDS) {
+            if ((L.flags & 8u) == 0u) return ~0ull;
+            if (L.unit_mode == RM_UNITS_LATTICE) return wave_cull_lattice(lunits, L.n_grp, x, y, z, thr, is_live, live_mask);
+            return wave_cull_blend(lunits, L.n_grp, L.unit_kmax, x, y, z, extra_margin, prune_scale, is_live, live_mask);
+        } else {
+            return ~0ull;
+        }
+    };
     // map_scene (wgsl:187-203) at one point per lane
-    auto eval_scene = [&](float x, float y, float z, float thr, unsigned long long live_mask) -> float {
+    auto eval_scene = [&](float x, float y, float z, float thr, bool is_live, unsigned long long live_mask) -> float {
         float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, v[1];
         SqrtGuard tiny;
         if constexpr (SPEC) {  // straight-line code compiled for this program's structure (rm_jit.h)
-            v[0] = map_scene_spec<true>(lprog_v, x, y, z, thr, live_mask, tiny, n_eval);
+            const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
+            v[0] = map_scene_spec<true>(lprog_v, x, y, z, need, live_mask, tiny, n_eval);
             if (tiny.any_bad()) {
                 // (an empty volatile asm keeps this a branch: for a program of one or two leaves the compiler otherwise
                 // evaluates both forms at every step and selects -- a second square root and 16 more vector instructions)
                 asm volatile("");
                 uint32_t again = 0u;
-                v[0] = map_scene_spec<false>(lprog_v, x, y, z, thr, live_mask, tiny, again);
+                v[0] = map_scene_spec<false>(lprog_v, x, y, z, need, live_mask, tiny, again);
             }
-        } else if (L.flags & 8u) {  // chain program (wave-uniform): the stack-free record loop, far pairs skipped
-            v[0] = map_scene_chain_pruned<true>(prog, L.n_rec, x, y, z, thr, live_mask, tiny);
-            if (tiny.any_bad()) v[0] = map_scene_chain_pruned<false>(prog, L.n_rec, x, y, z, thr, live_mask, tiny);
-        } else if (L.flags & 4u) {  // chain program, every record evaluated
-            v[0] = map_scene_chain<true>(prog, L.n_rec, x, y, z, tiny);
-            if (tiny.any_bad()) v[0] = map_scene_chain<false>(prog, L.n_rec, x, y, z, tiny);
+        } else if (L.flags & 4u) {  // chain program (wave-uniform): the stack-free record loop
+            const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
+            const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;  // (the unit records are staged in LDS with the program)
+            v[0] = map_scene_chain<true>(prog, L.n_rec, x, y, z, need, masked, tiny);
+            if (tiny.any_bad()) v[0] = map_scene_chain<false>(prog, L.n_rec, x, y, z, need, masked, tiny);
+        } else if (!EXT) {  // tree program -- reference node types in any arrangement, all a kernel without the extensions ever gets --:
+                            // one dispatch per record
+            const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;
+            if (masked) {
+                const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
+                const uint32_t* span = lunits + 4u * L.n_grp;  // row 4 of the unit table
+                v[0] = map_scene_tree<true, true>(prog, L.n_rec, spill, x, y, z, need, span, tiny);
+                if (tiny.any_bad()) v[0] = map_scene_tree<false, true>(prog, L.n_rec, spill, x, y, z, need, span, tiny);
+            } else {
+                v[0] = map_scene_tree<true, false>(prog, L.n_rec, spill, x, y, z, ~0ull, nullptr, tiny);
+                if (tiny.any_bad()) v[0] = map_scene_tree<false, false>(prog, L.n_rec, spill, x, y, z, ~0ull, nullptr, tiny);
+            }
+        } else if (PROG_IN_LDS && (L.flags & 8u)) {  // the general record loop; records of units the wave does not need are skipped
+            const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
+            map_scene_multi<1, true, Prog, EXT, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth, need, L.unit_mode);
+            if (tiny.any_bad())  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
+                map_scene_multi<1, false, Prog, EXT, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth, need, L.unit_mode);
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
-            if (tiny.any_bad())  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
-                map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
+            if (tiny.any_bad()) map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
         }
         return v[0];
     };
@@ -733,19 +802,15 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 
     // lane state of a marching ray: evaluation point = ro + d * sc
     float dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f;
-    uint32_t it = 0u, rid = 0u, mode = M_EMPTY;  // M_EMPTY (idle), M_MARCH, M_RETIRED (nothing left to take)
+    // itr: the ray's id in the pool (bits 0-9) and the march steps it has taken (bits 10 and up; max_iter <= 65536) in ONE
+    // register -- a step adds 1024, the loop bound compares with max_iter << 10 -- the one register between 6 and 5 waves per SIMD
+    uint32_t itr = 0u, mode = M_EMPTY;  // M_EMPTY (idle), M_MARCH, M_RETIRED (nothing left to take)
+    const uint32_t iter_limit = L.max_iter << 10;
     float thr_base = inf_f;  // SPEC: pruning threshold without its position term ("Pruning")
     // (a hit whose normal is being sampled keeps its state -- position, partial normal -- in LDS: tap phase, below)
     uint32_t rq_pos = 0u, rq_cnt = 0u, sq_n = 0u, hq_n = 0u;  // wave-uniform cursors: ready / miss / hit buffers
     uint32_t tap_t = TAP_IDLE, tap_n = 0u;                     // wave-uniform: tap phase step (TAP_IDLE = not in one), its entries
     bool pool_open = true;                                     // wave-uniform: the shared pool may still hold rays
-#ifdef RM_JIT_CACHED  // "Skip sets carried ALONG a ray"
-    unsigned long long cache_skip = 0ull;   // wave-uniform: units the last refresh skipped for every live lane
-    bool cache_valid = false;               // wave-uniform
-    float cache_gate = inf_f;               // wave-uniform: a refresh is due when most live lanes' thr_base fell below this
-    float cache_bs = -inf_f;                // per lane: sc at the refresh + the distance budget of its decisions
-    uint32_t cache_jstar = 0u;              // per lane: restart leaf (record index), 0 = none
-#endif
 
     auto flush_misses = [&]() {  // floor / black for every waiting ray that ended without a hit (<= 64): wgsl:117-130
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -805,7 +870,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         const uint32_t rank = lane_rank(want);
                         if (rank < avail) {
                             const uint32_t e = rq_pos + rank;
-                            rid = rq_rid[e];
+                            const uint32_t rid = rq_rid[e];
                             dx = rq_d[e]; dy = rq_d[V5_RQ + e]; dz = rq_d[2u * V5_RQ + e];
                             const bool finite_d = __builtin_fabsf(dx) < inf_f && __builtin_fabsf(dy) < inf_f && __builtin_fabsf(dz) < inf_f;
                             // The shared first step applies to finite rd that neither hit nor ended there (START_MARCH);
@@ -813,13 +878,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                             // inside a solid), which then goes through the ordinary hit path.
                             const bool shared = finite_d && start == START_MARCH;
                             sc = shared ? 0.0f + f0 : 0.0f;  // dist (wgsl:88), dist += scene_dist (wgsl:114)
-                            it = shared ? 1u : 0u;
+                            itr = rid | (shared ? 1024u : 0u);
                             thr_base = shared ? __builtin_fabsf(f0) * 2.00002f : inf_f;
                             mode = M_MARCH;
-#ifdef RM_JIT_CACHED
-                            cache_bs = -inf_f;  // a new ray: nothing is known about it, the next evaluation is a refresh
-                            cache_jstar = 0u;
-#endif
                         }
                     }
                     rq_pos += n_want < avail ? n_want : avail;
@@ -869,16 +930,15 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             // |F(tap)| <= |sd_hit| + eps sqrt(3) + error: the threshold of a tap ("Pruning"); the far test runs at c,
             // another eps sqrt(3) and one more leaf-evaluation error away from every tap
             const float m = kPruneAbs * (prune_scale + (((__builtin_fabsf(cx) + __builtin_fabsf(cy)) + __builtin_fabsf(cz)) + 1.0e-3f));
-#ifdef RM_JIT_BLEND_PRUNE  // the local rule has no threshold: its margin, plus the distance from c to a tap (twice over, as above)
-            const float thr_c = 3.5e-4f + (m + m);
-#else
             const float thr_c = __uint_as_float(hq_rid[e] & ~1023u) * 1.00001f + 3.5e-4f + (m + m);
-#endif
             float f[4];
             SqrtGuard tiny;
             const unsigned long long live4_m = __builtin_amdgcn_ballot_w64(live4);
-            map_scene_taps<true>(lprog_v, cx, cy, cz, thr_c, live4_m, tiny, f);
-            if (tiny.any_bad()) map_scene_taps<false>(lprog_v, cx, cy, cz, thr_c, live4_m, tiny, f);
+            // the units are decided at the hit positions c, eps sqrt(3) from every tap: the threshold (lattice programs) or
+            // the margin (programs that blend) carries that distance twice over
+            const unsigned long long need4 = units_needed(cx, cy, cz, thr_c, 3.5e-4f, live4, live4_m);
+            map_scene_taps<true>(lprog_v, cx, cy, cz, need4, live4_m, tiny, f);
+            if (tiny.any_bad()) map_scene_taps<false>(lprog_v, cx, cy, cz, need4, live4_m, tiny, f);
             n_iter++;
             n_live += (uint32_t)__popcll(live4_m);
             // n = ((k0 f0 + k1 f1) + k2 f2) + k3 f3, k = (+,-,-), (-,-,+), (-,+,-), (+,+,+); products with +-1 are exact
@@ -889,7 +949,10 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
                 tap_t = 4u;  // the material phase follows
             } else {
-                if (live4) res[hq_rid[e] & 1023u] = shade_hit(nx, ny, nz, cx, cy, cz);  // wgsl:98-103
+                // (the hit position is read again rather than kept in three registers through the four-tap function, whose
+                // pressure is the kernel's peak: the acquire keeps the compiler from forwarding the earlier loads)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (live4) res[hq_rid[e] & 1023u] = shade_hit(nx, ny, nz, hq_v[e], hq_v[V5_HQ + e], hq_v[2u * V5_HQ + e]);  // wgsl:98-103
                 tap_t = TAP_IDLE;
             }
             continue;
@@ -916,9 +979,6 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             is_live = mode == M_MARCH;
             thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
         }
-#ifdef RM_JIT_BLEND_PRUNE  // the local rule (spec_local_near) takes only the float margin m, at march steps and taps alike
-        thr = kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
-#endif
         n_iter++;
         const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
         n_live += (uint32_t)__popcll(live_m);
@@ -927,55 +987,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
         // issue priority: the chain runs at the lone-wave rate and the short rays fill in behind it.
         if (!tapping) {
-            const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && it >= RM_PRIO_LONG_RAYS));
+            const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && itr >= (RM_PRIO_LONG_RAYS << 10)));
             if (old_rays != 0u) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
         }
 #endif
-#ifdef RM_JIT_CACHED
-        float sd;
-        if (!tapping) {
-            // Is what the last refresh decided still good for every live lane (budget), and is it still worth using (the rays
-            // have not come so much closer that a new look would skip a lot more)?
-            const unsigned long long stale = __builtin_amdgcn_ballot_w64(!(cache_bs > sc + thr)) & live_m;  // NaN: stale
-            const uint32_t n_closer = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(thr_base < cache_gate) & live_m);
-            bool refresh = !cache_valid || stale != 0ull || 2u * n_closer > (uint32_t)__popcll(live_m);
-            sd = 0.0f;
-            if (!refresh) {
-                SqrtGuard tiny;
-                sd = map_scene_cached<true>(lprog_v, ex, ey, ez, cache_skip, cache_jstar, live_m, tiny, n_eval);
-                if (tiny.any_bad()) refresh = true;  // a square root outside the short form's range: the refresh has the generic one
-            }
-            if (refresh) {
-                asm volatile("");
-                SpecCache cache;
-                // worth remembering: decisions whose slack covers about one more step (thr_base is 2 |sd| of the step that led
-                // here) on top of the float margin
-                cache.tau = thr_base * 0.5f + thr;
-                SqrtGuard tiny;
-                sd = map_scene_refresh<true>(lprog_v, ex, ey, ez, thr, live_m, tiny, n_eval, cache);
-                if (tiny.any_bad()) {
-                    asm volatile("");
-                    SpecCache again;
-                    again.tau = cache.tau;
-                    sd = map_scene_refresh<false>(lprog_v, ex, ey, ez, thr, live_m, tiny, n_eval, again);
-                    cache = again;
-                }
-                cache_skip = cache.skip;
-                cache_jstar = cache.jstar;
-                cache_bs = sc + cache.budget;
-                cache_valid = true;
-                cache_gate = 0.5f * __uint_as_float(wave_max_u32(is_live && thr_base == thr_base ? __float_as_uint(thr_base) : 0u));
-#ifdef RM_JIT_COUNT_REFRESH  // statistics (RM_JIT_PRUNE_STATS=5): refreshes instead of leaves
-                n_eval += 1u;
-#endif
-            }
-        } else {
-            sd = eval_scene(ex, ey, ez, thr, live_m);
-        }
-#else
-        const float sd = eval_scene(ex, ey, ez, thr, live_m);
-#endif
+        const float sd = eval_scene(ex, ey, ez, thr, is_live, live_m);
 
         if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
             const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
@@ -1002,11 +1019,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         const unsigned long long esc_m = on_m & __ballot(sd > L.max_dist);                            // wgsl:109-111
         const unsigned long long go_m = on_m & ~esc_m;
         sc = select_by_mask(sc, sc + sd, go_m);                                                       // wgsl:114
-        it = select_by_mask(it, it + 1u, go_m);
+        itr = select_by_mask(itr, itr + 1024u, go_m);
 #ifdef RM_PRUNE_PLUMBING  // only pruning kernels read it
         thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
 #endif
-        const unsigned long long miss_mask = esc_m | (go_m & __ballot(it >= L.max_iter));             // loop bound, wgsl:90
+        const unsigned long long miss_mask = esc_m | (go_m & __ballot(itr >= iter_limit));             // loop bound, wgsl:90
         const bool hit = is_live && sd < L.min_dist, miss = lane_of(miss_mask, lane);
         if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
             if (hit) {
@@ -1014,9 +1031,9 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 #ifdef RM_PRUNE_PLUMBING
                 // |sd| of the hit, rounded up to 22 bits, rides in the upper bits of the entry's ray id (< 1024): the
                 // pruning threshold of its normal taps ("Pruning"); a NaN stays a NaN (nothing is skipped then)
-                hq_rid[e] = rid | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);
+                hq_rid[e] = (itr & 1023u) | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);
 #else
-                hq_rid[e] = rid;
+                hq_rid[e] = itr & 1023u;
 #endif
                 hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
                 mode = M_EMPTY;
@@ -1028,7 +1045,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             if (sq_n + n_miss > V5_SQ) flush_misses();
             if (miss) {
                 const uint32_t e = sq_n + lane_rank(miss_mask);
-                sq_rid[e] = rid;
+                sq_rid[e] = itr & 1023u;
                 sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
                 mode = M_EMPTY;
             }
@@ -1100,8 +1117,11 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 // The interpreter for reference-only programs staged in LDS -- north_star's design, and what runs while a structure compiles --
 // with its vector registers capped at 80 (6 waves per SIMD, which is also what its LDS footprint allows): left alone the
 // allocator takes 81 and a sixth of the occupancy (march kernel of the metric frame 0.83 -> 0.87 ms).
+#ifndef RM_LEAN_WAVES
+#define RM_LEAN_WAVES 6
+#endif
 template <int WPT>
-__global__ __launch_bounds__(64 * WPT) __attribute__((amdgpu_waves_per_eu(6, 8)))
+__global__ __launch_bounds__(64 * WPT) __attribute__((amdgpu_waves_per_eu(RM_LEAN_WAVES, 8)))
 void rm_render_v5_lean(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
     rm_render_v5_body<ProgLds, true, WPT, false, false, false>(L, work, n_tiles, refill_min);
 }

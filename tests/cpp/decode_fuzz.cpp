@@ -66,7 +66,17 @@ static int check(const RmDecoded& d) {
     }
     if (!d.has_xforms && (cones != d.n_sphere || slabs != d.n_box)) return 6;
     if (d.has_xforms && d.bounds.size() != (size_t)d.n_sphere * 4u) return 7;
-    if (d.groups.size() > d.rec.size() / 2u) return 8;
+    // unit records of wave-level culling: at most 64, none without a mode, one per bounded leaf of a lattice program, kinds in range,
+    // an outer radius that is never below the inner one
+    if (d.units.size() > 64u || (d.unit_mode == RM_UNITS_NONE) != d.units.empty()) return 8;
+    if (d.unit_mode == RM_UNITS_LATTICE && (d.units.size() != d.n_leaves + 0u && d.units.size() < d.n_leaves)) return 12;
+    for (const RmRecord& g : d.units) {
+        uint32_t k;
+        std::memcpy(&k, &g.p[6], 4);
+        if (k > RM_UNIT_LEAF || (d.unit_mode == RM_UNITS_LATTICE) != (k == RM_UNIT_LEAF)) return 13;
+        if (g.p[3] < g.p[4]) return 14;          // (NaN compares false: a leaf with a NaN size has bounds +inf / -inf)
+        if (!(g.p[5] >= 0.0f) || g.p[5] > d.unit_kmax) return 15;
+    }
     if (d.is_chain && d.spill_depth != 0u) return 9;
     if (d.bound_walk && (d.has_xforms || d.spill_depth > 1u)) return 10;
     if (d.max_depth > 32u) return 11;

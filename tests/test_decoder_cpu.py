@@ -19,16 +19,16 @@ def test_metric_scenes(oracle):
     g32 = info(oracle, *scenes.g32())
     # 16 primitives in a left-deep chain, every operator fused into its right operand's record; every fourth operator is a
     # Subtraction: its three primitives are not in the miss-test tables (max(a, -b) >= a)
-    assert g32["records"] == 16 and g32["is_chain"] == 1 and g32["prunable"] == 1 and g32["groups"] == 8
+    assert g32["records"] == 16 and g32["is_chain"] == 1 and g32["prunable"] == 1 and g32["groups"] == 16      # one culling unit per leaf
     assert g32["subtracted_leaves"] == 3 and g32["cones"] + g32["slabs"] == 13
     assert g32["spill_depth"] == 0 and g32["bound_walk"] == 0 and g32["has_xforms"] == 0
     g64 = info(oracle, *scenes.g64())
-    assert g64["records"] == 32 and g64["groups"] == 16 and g64["subtracted_leaves"] == 7 and g64["cones"] + g64["slabs"] == 25
+    assert g64["records"] == 32 and g64["groups"] == 32 and g64["subtracted_leaves"] == 7 and g64["cones"] + g64["slabs"] == 25
     g8 = info(oracle, *scenes.g8())          # ((S u B) - S) u B
     assert g8["records"] == 4 and g8["is_chain"] == 1 and g8["subtracted_leaves"] == 1 and (g8["cones"], g8["slabs"]) == (1, 2)
     bal = info(oracle, *scenes.g32_balanced())
     assert bal["is_chain"] == 0 and bal["prunable"] == 1 and bal["records"] == 16 + 7   # 8 fused pairs, 7 operators on sub-trees
-    assert info(oracle, *scenes.g1()) == dict(records=1, cones=1, slabs=0, subtracted_leaves=0, groups=0, spill_depth=0, is_chain=1,
+    assert info(oracle, *scenes.g1()) == dict(records=1, cones=1, slabs=0, subtracted_leaves=0, groups=1, spill_depth=0, is_chain=1,
                                                prunable=1, bound_walk=0, has_xforms=0, leaves=1, auto_pruned=0)
     assert g32["leaves"] == 16 and g32["auto_pruned"] == 1 and g64["leaves"] == 32 and g8["leaves"] == 4 and g8["auto_pruned"] == 0
 
@@ -94,6 +94,31 @@ def test_which_programs_get_the_miss_test_on_lower_bounds(oracle):
     assert i["spill_depth"] >= 2 and i["bound_walk"] == 0 and i["prunable"] == 0
     t = scenes._Tab()
     assert info(oracle, t.nodes, t.scale(t.smooth_union(t.sphere((0, 0, 0), 1), t.sphere((1, 0, 0), 0.5), 0.3), 2.0))["bound_walk"] == 0
+
+
+def test_units_of_wave_level_culling(oracle):
+    """Which programs get unit records (rm_units.h): lattice programs one per bounded leaf; programs that blend one per step of
+    their top-level chain, if the top level is a chain; nothing beyond 64 units, with transforms, or for a blend at the root of
+    two sub-trees."""
+    g32s = info(oracle, *scenes.EXT_SCENES["g32s"]())
+    assert g32s["groups"] == 16 and g32s["prunable"] == 0 and g32s["auto_pruned"] == 2      # start + 12 blends + 3 subtractions
+    t = scenes._Tab()      # a sub-tree as the right operand of a blend: one opaque unit; the chain has 3 units
+    i = info(oracle, t.nodes, t.smooth_union(t.smooth_union(t.sphere((0, 0, 0), 1), t.box((1, 0, 0), (0.4, 0.4, 0.4)), 0.2),
+                                             t.op(U, t.sphere((2, 0, 0), 0.5), t.sphere((2.5, 0, 0), 0.4)), 0.3))
+    assert i["groups"] == 3 and i["auto_pruned"] == 0       # (3 units, 4 leaves: below the automatic cut)
+    t = scenes._Tab()      # a balanced tree of blends: record 0 starts a sub-tree, but the root's right operand is one as well:
+    lv = [t.sphere((float(k), 0, 0), 0.4) for k in range(4)]      # start, blend, opaque(sub-tree + its blend)
+    i = info(oracle, t.nodes, t.smooth_union(t.smooth_union(lv[0], lv[1], 0.3), t.smooth_union(lv[2], lv[3], 0.3), 0.3))
+    assert i["groups"] == 3
+    t = scenes._Tab()      # 40 leaves under min / max: 40 units; 70 would be more than the mask has bits for (and more than the
+    acc = t.sphere((0.0, 0.0, 0.0), 0.3)      # reference's 1 KiB command buffer holds)
+    for k in range(1, 40):
+        acc = t.op(U, acc, t.sphere((0.5 * k, 0.0, 0.0), 0.3))
+    assert info(oracle, t.nodes, acc)["groups"] == 40
+    t = scenes._Tab()      # a translated blend: no units
+    assert info(oracle, t.nodes, t.translation(t.smooth_union(t.sphere((0, 0, 0), 1), t.sphere((1, 0, 0), 0.5), 0.3), (0.1, 0, 0)))["groups"] == 0
+    t = scenes._Tab()      # a Plane in a min / max program: not prunable, no units
+    assert info(oracle, t.nodes, t.op(U, t.sphere((0, 0, 0), 1), t.plane((0.0, 1.0, 0.0), 1.5)))["groups"] == 0
 
 
 def test_invalid_programs_report_the_validators_status():

@@ -74,3 +74,39 @@ def test_primitive_ops_match_the_oracle_definitions(res):
     for name, ok in checks.items():
         bad = np.nonzero(~ok)[0]
         assert bad.size == 0, "%s differs for a=%r b=%r" % (name, a[bad[:4]], b[bad[:4]])
+
+
+def test_cross_lane_primitives_of_wave_level_culling(res):
+    """wave_max_u32 (quad_perm / row_half_mirror / row_mirror + four readlanes) and wave_exclusive_min (row_shr 1,2,3,4,8 +
+    row_bcast 15 / 31 + one shift) -- the DPP row operations wave-level culling builds its ball and its prefix bounds from --
+    against numpy on random and adversarial waves: the maximum anywhere in the wave, a NaN among the inputs (its bit pattern
+    wins the maximum: nothing may then be culled; the minimum skips it), +inf, runs of equal values, one value per lane."""
+    rng = np.random.default_rng(99)
+    waves = []
+    for k in range(64):                                   # the maximum / a unique minimum at every lane position
+        w = rng.uniform(1.0, 2.0, 64).astype(F)
+        w[k] = 3.0
+        w[(k * 7 + 3) % 64] = 0.25
+        waves.append(w)
+    for _ in range(200):
+        w = np.abs(rng.normal(size=64)).astype(F) * F(rng.choice([1e-3, 1.0, 1e6]))
+        sel = rng.random(64)
+        w[sel < 0.05] = np.inf
+        w[(sel > 0.05) & (sel < 0.08)] = 0.0
+        if rng.random() < 0.3:
+            w[rng.integers(64)] = np.nan
+        waves.append(w)
+    waves.append(np.full(64, np.inf, F))
+    waves.append(np.arange(64, 0, -1).astype(F))         # strictly decreasing: every lane is a new minimum
+    waves.append(np.arange(64).astype(F))
+    a = np.ascontiguousarray(np.stack(waves))
+    n = a.shape[0]
+    out = np.zeros((2, n, 64), dtype=F)
+    _ffi.check(res._h, _ffi.hip_lib().rm_selftest_wave(res._h, a.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+    exp_max = a.view(np.uint32).max(axis=1)               # by bit pattern: non-negative floats order like their bits, a NaN is above +inf
+    assert (out[0].view(np.uint32) == exp_max[:, None]).all()
+    with np.errstate(all="ignore"):
+        run = np.fmin.accumulate(a, axis=1)              # fmin skips a NaN
+    exp_min = np.concatenate([np.full((n, 1), np.inf, F), run[:, :-1]], axis=1)
+    exp_min = np.where(np.isnan(exp_min), np.inf, exp_min).astype(F)     # (a wave that starts with a NaN: nothing below but NaNs)
+    assert _same(out[1], exp_min).all(), np.argwhere(~_same(out[1], exp_min))[:5]

@@ -115,9 +115,10 @@ def test_deep_stack_programs(res, oracle, kernel):
 @pytest.mark.parametrize("kernel", [_ffi.RM_KERNEL_V5, _ffi.RM_KERNEL_V5_LDS], ids=["v5", "v5_lds"])
 def test_interpreter_record_loops(res, oracle, kernel):
     """Which record loop the interpreter kernels take (RM_INFO_INTERPRETER_LOOP) and that each renders the oracle's image:
-    chains "a op b op c ..." of 1..9 primitives -- the stack-free loop with far pairs skipped (odd lengths leave a last
-    record without a pair, length 1 has no pair at all) -- seen from outside, from inside a primitive and from far away;
-    anything else (a right-deep tree, an operator on two sub-trees, a trailing second value) the general loop."""
+    chains "a op b op c ..." of 1..9 primitives -- the stack-free loop over the records the wave's unit mask names --
+    seen from outside, from inside a primitive and from far away;
+    other arrangements of reference nodes (a right-deep tree, operators on sub-trees) the tree loop -- which steps over a whole
+    right operand when the wave needs none of its leaves --, extension node types the general loop."""
     rng = np.random.default_rng(11)
     W, H = 56, 40
     lim = (0.01, 100.0, 96)
@@ -138,12 +139,23 @@ def test_interpreter_record_loops(res, oracle, kernel):
             u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
             setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
             assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
-            assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0 and res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 2, n
+            # (chains of fewer than a dozen leaves walk every record: the mask would cost more than it saves)
+            assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0 and res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 1, n
+    # a chain of 16: over the records the wave's unit mask names, where the unit records are at hand (LDS)
+    cc, w, u = oracle_case(oracle, scenes.g32(), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+    assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == (2 if kernel == _ffi.RM_KERNEL_V5_LDS else 1)
     for scene in (scenes.right_deep(5), scenes.g32_balanced()):
         cc, w, u = oracle_case(oracle, scene, W, H, None)
         setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
         assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
-        assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
+        assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 3        # trees of reference nodes: one dispatch per record
+    # ... and anything with an extension node type the general loop
+    cc, w, u = oracle_case(oracle, scenes.EXT_SCENES["ext_mix"](), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+    assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
     # a specialised kernel reports 0 as well (the loop is the interpreter's)
     cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=KERNEL_SPEC)
@@ -1026,17 +1038,17 @@ def test_draw_is_stream_capturable(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("form", ["generated", "leaf_tests", "tested_at_every_step", "tested_at_every_step_leaf_tests"])
-def test_local_skipping_rule_of_blending_programs(oracle, form):
-    """Programs that blend skip a leaf (or a pair) whose lower bound is at least k above the accumulator it would be blended
-    into, for every live lane (rm_groups.h, rm_kernel_v5.h spec_local_near): exact only if "at least k above" is decided on
-    the safe side of every rounding.  Scenes built to sit ON the boundary and around it: concentric spheres whose radii differ
-    by exactly k (the second leaf's value is the accumulator + k up to an ulp, everywhere), staircases of leaves each within k
-    of the previous accumulator (every one matters although all but the last are far above the final value), k = 0 / negative /
-    1e-6 / larger than the scene, partners that coincide or are 40 units apart, everything 1000 units from the origin, Unions,
-    Subtractions and an Intersection mixed into the chain -- and the parameters (k included, through zero) moving under ONE
-    compiled kernel.  The default form also carries its decisions ALONG the ray (skip sets with a distance budget, restarts:
-    rm_kernel_v5.h): the staircases and the grazing views are where a budget runs out between two steps."""
+@pytest.mark.parametrize("form", ["generated", "generated_without_subtractor_tests", "interpreter"])
+def test_culling_rules_of_blending_programs(oracle, form):
+    """Programs that blend along a top-level chain are culled per wave (rm_kernel_v5.h "Wave-level culling", rm_units.h): a unit
+    whose leaf is at least k above every value the accumulator can have is skipped, one at least k below restarts the chain,
+    a subtractor or an intersection that cannot change the accumulator is skipped -- exact only if "at least k" is decided on
+    the safe side of every rounding and every bound.  Scenes built to sit ON the boundaries and around them: concentric
+    spheres whose radii differ by exactly k (the second leaf's value is the accumulator + k up to an ulp, everywhere),
+    staircases of leaves each within k of the previous accumulator (every one matters although all but the last are far above
+    the final value), k = 0 / negative / 1e-6 / larger than the scene, leaves that coincide or are 40 units apart, everything
+    1000 units from the origin, Unions, Subtractions and an Intersection mixed into the chain, sub-trees and a cylinder and a
+    plane as opaque units -- and the parameters (k included, through zero) moving under ONE compiled kernel."""
     import math
     rng = np.random.default_rng(4242)
     W, H = 80, 56
@@ -1090,12 +1102,12 @@ def test_local_skipping_rule_of_blending_programs(oracle, form):
         r.set_option(_ffi.RM_OPT_SPECIALIZE, 2)
         r.set_option(_ffi.RM_OPT_PRUNE, 1)
         r.resize_command_buffer(4096)
-        # knobs of the generator, read when a structure is generated (and part of the kernel cache's key): members of a near pair
-        # with a test of their own; no skip sets carried along the ray (every evaluation runs the tests)
-        if form.endswith("leaf_tests"):
-            os.environ["RM_JIT_BLEND_LEAF_TESTS"] = "1"
-        if form.startswith("tested_at_every_step"):
-            os.environ["RM_JIT_CACHED"] = "0"
+        # a knob of the generator, read when a structure is generated (and part of the kernel cache's key): subtracted leaves
+        # without their local test
+        if form == "generated_without_subtractor_tests":
+            os.environ["RM_JIT_SUB_TESTS"] = "0"
+        if form == "interpreter":
+            r.set_option(_ffi.RM_OPT_SPECIALIZE, 0)
         for offset in ((0.0, 0.0, 0.0), (800.0, -300.0, 500.0)):
             for kscale in (1.0, 0.0, -1.0):                  # the same structures again with every k scaled: same compiled kernels
                 for name, (nodes, root) in cases(offset, kscale).items():
@@ -1112,14 +1124,14 @@ def test_local_skipping_rule_of_blending_programs(oracle, form):
                             for cull in (1, 0):
                                 r.set_option(_ffi.RM_OPT_CULL, cull)
                                 img = r.draw(W, H)
-                                assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 2, (name, r.jit_log())
+                                if form != "interpreter":
+                                    assert r.info(_ffi.RM_INFO_SPECIALIZED) == 1 and r.info(_ffi.RM_INFO_PRUNED) == 2, (name, r.jit_log())
                                 if img.tobytes() != ref.tobytes():
                                     bad = np.argwhere((img.view(np.uint32) != ref.view(np.uint32)).any(axis=-1))
                                     raise AssertionError("%s offset %s kscale %g events %s limits %s cull %d: %d pixels differ (first %s)"
                                                          % (name, offset, kscale, events, lim, cull, len(bad), bad[:3].tolist()))
     finally:
-        os.environ.pop("RM_JIT_BLEND_LEAF_TESTS", None)
-        os.environ.pop("RM_JIT_CACHED", None)
+        os.environ.pop("RM_JIT_SUB_TESTS", None)
         r.close()
 
 

@@ -22,7 +22,8 @@ def map_scene_body(src):
 
 def test_generated_code_follows_the_postfix_program(oracle):
     """One leaf evaluation per primitive in program order, one combine per operator, operands resolved like the
-    value stack of ray_marching.wgsl:187-203 would; sphere / box leaves sit behind the wave-uniform far test."""
+    value stack of ray_marching.wgsl:187-203 would; in the pruned form every sphere / box leaf sits behind its bit of the
+    wave's unit mask."""
     cc, w = serialize(oracle, scenes.g8())     # ((S u B) - S) u B
     plain = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w))]
     assert plain == [
@@ -35,29 +36,29 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "return v3;",
     ]
     body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True))]
-    assert body[:4] == ["const float thrk = thr * 1.000005f;", "const float thr2k = (thr * thr) * 1.00001f;",
-                        "const float inf = __uint_as_float(0x7F800000u);", "const float x0 = qx, y0 = qy, z0 = qz;"]
-    assert body[4:] == [
-        # consecutive sphere / box leaves share a bounding-sphere test: group record g follows the 4 program records
-        # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
-        "const bool g0 = spec_group_near(live, lp + 32, x0, y0, z0, thrk);",
-        "const bool g1 = spec_group_near(live, lp + 40, x0, y0, z0, thrk);",
+    assert body == [
+        # every bounded leaf is a UNIT behind one bit of `need`, the mask wave-level culling computed for the whole wave
+        # (rm_kernel_v5.h); skipped, a pushed leaf is +inf and a fused one leaves the accumulator alone
+        "const float inf = __uint_as_float(0x7F800000u);",
+        "const float x0 = qx, y0 = qy, z0 = qz;",
         "float v0 = inf;",
-        "if (g0)",
-        "{ v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny); }",     # a sphere of a near pair: no test of its own
+        "if (unit_needed(need, 0u)) {",
+        "v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);",      # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
+        "}",
         "float v1 = v0;",
-        "if (g0)",
-        "{ const SpecBox b = spec_box_a(lp + 8, x0, y0, z0);",
-        "if (spec_any_near(live, b.a > thr2k)) { v1 = vmin(v0, spec_box_v<FAST>(b, tiny)); } }",
+        "if (unit_needed(need, 1u)) {",
+        "v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
+        "}",
         "float v2 = v1;",
-        "if (g1)",
+        "if (unit_needed(need, 2u)) {",
         # a SUBTRACTED leaf: evaluated only if some live lane is inside it, or inside the accumulated solid (max(acc, -v) = acc else)
-        "{ const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
-        "if (spec_sub_sphere_near(live, lp + 16, a, v1)) { v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny)); } }",
+        "const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
+        "if (spec_sub_sphere_near(live, lp + 16, a, v1)) v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny));",
+        "}",
         "float v3 = v2;",
-        "if (g1)",
-        "{ const SpecBox b = spec_box_a(lp + 24, x0, y0, z0);",
-        "if (spec_any_near(live, b.a > thr2k)) { v3 = vmin(v2, spec_box_v<FAST>(b, tiny)); } }",
+        "if (unit_needed(need, 3u)) {",
+        "v3 = vmin(v2, spec_box<FAST>(lp + 24, x0, y0, z0, tiny));",
+        "}",
         "__builtin_amdgcn_sched_barrier(0);",
         "return v3;",
     ]
@@ -65,7 +66,7 @@ def test_generated_code_follows_the_postfix_program(oracle):
 
 def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
     """Interpret the generated straight-line code with plain float64 SDFs: a structural check only.
-    prune_all_far(value) -> bool decides whether a leaf counts as far for the (single) lane."""
+    prune_all_far(value) -> bool decides whether a leaf counts as far (its unit's bit of `need` clear) for the (single) lane."""
     import math
 
     def sphere(rec):
@@ -77,37 +78,38 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
         q = [abs(pos[i] - p[i]) - p[3 + i] for i in range(3)]
         return math.sqrt(sum(max(x, 0.0) ** 2 for x in q)) + min(max(q), 0.0)
 
+    def leaf(kind, off):
+        return sphere(int(off) // 8) if kind == "sphere" else box(int(off) // 8)
+
     ops = {"vmin": min, "vmax_negb": lambda a, b: max(a, -b), "fmax_": max}
     env = {"inf": math.inf}
     pending = None
-    for line in body:
-        line = line.strip()
-        if line.startswith(("const float thr", "const float inf", "const float x0", "__builtin_amdgcn_sched_barrier")):
+    lines = [l.strip() for l in body]
+    i = 0
+    while i < len(lines):
+        line = lines[i]
+        i += 1
+        if line.startswith(("const float inf", "const float x0", "__builtin_amdgcn_sched_barrier")) or line == "}":
             continue
-        if re.match(r"const bool g\d+ = spec_group_near\(live, lp \+ \d+, x0, y0, z0, thrk\);$", line) \
-                or re.match(r"if \(g\d+\)$", line):
-            continue      # group tests: a group that is far implies each member is (tests/test_gpu_* check the spheres)
         if line.startswith("return"):
             return env[line.rstrip(";").split()[1]]
         m = re.match(r"float (v\d+) = (\w+);", line)
         if m:
             env[m.group(1)] = env[m.group(2)]
             continue
-        m = re.match(r"\{ const (?:float a = spec_sphere_a|SpecBox b = spec_box_a)\(lp \+ (\d+),", line)
-        if m:
-            rec = int(m.group(1)) // 8
-            pending = sphere(rec) if "sphere" in line else box(rec)
-            continue
-        m = re.match(r"if \(spec_(?:any_near|sub_sphere_near|sub_box_near)\(.*?\)\) \{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)_v<FAST>\(.*?\)\)?; \} \}", line)
-        if m:
-            tgt, op, acc = m.groups()
-            if not (prune_all_far and prune_all_far(pending)):
-                env[tgt] = pending if op is None else ops[op](env[acc], pending)
-            continue
-        m = re.match(r"\{ (v\d+) = (?:(\w+)\((v\d+), )?spec_(sphere|box)<FAST>\(lp \+ (\d+), x0, y0, z0, tiny\)\)?; \}$", line)
-        if m:             # member of a pair without a far test of its own (spheres): evaluated whenever its pair is near
-            tgt, op, acc, kind, off = m.groups()
-            val = sphere(int(off) // 8) if kind == "sphere" else box(int(off) // 8)
+        m = re.match(r"if \(unit_needed\(need, \d+u\)\) \{$", line)
+        if m:             # one unit = one leaf: find its value, then decide whether the lane skips it
+            block = []
+            while lines[i] != "}":
+                block.append(lines[i])
+                i += 1
+            text = " ".join(block)
+            k = re.search(r"spec_(sphere|box)(?:_a|<FAST>)\(lp \+ (\d+),", text)
+            val = leaf(k.group(1), k.group(2))
+            if prune_all_far and prune_all_far(val):
+                continue
+            a = re.search(r"(v\d+) = (?:(\w+)\((v\d+), )?spec_(?:sphere|box)(?:_v)?<FAST>", text)
+            tgt, op, acc = a.groups()
             env[tgt] = val if op is None else ops[op](env[acc], val)
             continue
         m = re.match(r"const float (v\d+) = (\w+)\((v\d+), (v\d+)\);", line)
@@ -233,6 +235,35 @@ def test_disk_cache_of_compiled_kernels(oracle, tmp_path):
         assert run("g8")[2] == "loaded"
 
 
+def test_disk_cache_is_on_by_default_next_to_the_library(oracle):
+    """Without RM_JIT_CACHE_DIR the compiled kernels live in jit_cache/ next to librm_hip.so (build() leaves the BASELINE scenes'
+    kernels there); RM_JIT_CACHE_DIR=off compiles every time."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ray_marching_amd import csg, renderer\n"
+            "cc, w = csg.serialize(csg.scene('g8'))\n"
+            "rc, ms, n, log = renderer.jit_compile(cc, w)\n"
+            "print(rc, 'nohiprtc' if 'could not be loaded' in log else log.strip().splitlines()[-1] if log.strip() else 'compiled')\n" % root)
+
+    def run(**env):
+        e = {k: v for k, v in os.environ.items() if k != "RM_JIT_CACHE_DIR"}
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=e, timeout=300)
+        assert r.returncode == 0, r.stderr
+        return r.stdout.strip()
+
+    first = run()
+    if "nohiprtc" in first:
+        pytest.skip("libhiprtc is not installed")
+    second = run()
+    assert second.startswith("0 loaded from ") and os.path.join("ray-marching_amd", "jit_cache", "rm_") in second, second
+    assert run(RM_JIT_CACHE_DIR="off") == "0 compiled"
+    assert run(RM_JIT_CACHE_DIR="") == "0 compiled"
+
+
 def test_four_taps_in_one_pass_function(oracle):
     """Generated kernels take the four normal taps of a hit (wgsl:135-144) in one pass: every record applied to the four
     positions c + k_t eps, in the pruned form behind ONE far test at the hit position.  Programs with a SmoothUnion
@@ -256,15 +287,12 @@ def test_four_taps_in_one_pass_function(oracle):
     assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
     pruned = taps_body(renderer.jit_source(cc, w, prune=True))
     k = pruned.index("float v0_0 = inf;")
-    assert pruned[k - 2:k] == ["const bool g0 = spec_group_near(live, lp + 32, cx, cy, cz, thrk);",
-                               "const bool g1 = spec_group_near(live, lp + 40, cx, cy, cz, thrk);"]
-    assert pruned[k:k + 10] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
-                                "if (g0 && spec_any_near(live, spec_sphere_far(lp + 0, spec_sphere_a(lp + 0, cx, cy, cz), thrk))) {",
+    assert pruned[k:k + 11] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
+                                "if (unit_needed(need, 0u)) {",       # one bit of the wave's unit mask for the four taps of a leaf
                                 "v0_0 = spec_sphere<FAST>(lp + 0, x0_0, y0_0, z0_0, tiny);",
                                 "v0_1 = spec_sphere<FAST>(lp + 0, x0_1, y0_1, z0_1, tiny);",
                                 "v0_2 = spec_sphere<FAST>(lp + 0, x0_2, y0_2, z0_2, tiny);",
-                                "v0_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}"]
-    assert pruned[k + 10] == "guard_fence(tiny);"
+                                "v0_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}", "guard_fence(tiny);"]
     # transforms: every scope gets four positions; smooth unions: the four blends behind ONE blend-zone test
     cc, w = serialize(oracle, scenes.xform_mix())
     src = renderer.jit_source(cc, w)
