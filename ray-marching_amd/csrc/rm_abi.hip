@@ -179,6 +179,7 @@ int ensure_program(rm_ctx* c, hipStream_t s) {
     // the unit records of wave-level culling (RmDecoded::units) follow the program's records in the same buffer
     std::vector<RmRecord> image = d.rec;
     image.insert(image.end(), d.units.begin(), d.units.end());
+    image.insert(image.end(), d.tree.begin(), d.tree.end());  // ... and the operand masks of a tree program's records (RmDecoded::tree)
     if (image.size() > c->d_prog_cap) {
         if (c->d_prog) (void)hipFree(c->d_prog);
         c->d_prog = nullptr;
@@ -368,15 +369,21 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     const bool chain = c->decoded.is_chain && chain_mode > 0;
     // ... and whether the interpreter uses the wave-level culling mask (bit 3): 2 (default) yes, wherever the program has units
     // Measured (profiles/r03_interpreter_loops.txt): over a chain the mask names the records to fetch at all -- 64-node scene at 4K
-    // 15.5 -> 5.3 ms, metric scene 1.23 -> 0.71 ms --, but it has a fixed price per evaluation (~250 cycles) that four leaves
-    // do not repay (8-node scene 0.44 -> 0.66 ms), and in the tree and general loops, where a skipped record is still fetched
-    // and decoded, it loses (balanced 32-node tree 1.85 -> 2.32 ms, the blended scene 4.0 -> 4.4): chains of a dozen leaves or more.
-    const bool units = c->decoded.unit_mode == RM_UNITS_LATTICE && chain && chain_mode >= 2 && c->decoded.n_leaves >= kPruneLeaves;
+    // 15.5 -> 5.3 ms, metric scene 1.23 -> 0.71 ms --, and over a tree the records that are left once operands without a needed
+    // leaf are dropped with their operators (map_scene_tree_masked); but it has a fixed price per evaluation (~250 cycles) that four
+    // leaves do not repay (8-node scene 0.44 -> 0.66 ms), and in the general loop, where a skipped record is still fetched and
+    // decoded, it loses (the blended scene 4.0 -> 4.4): chains and trees of a dozen leaves or more.
     // bit 4: tree program (every record one of the eight fast shapes): the interpreter's one-dispatch-per-record loop.  RM_CHAIN_MODE=0
     // keeps the general loop for everything (diagnostics)
     const bool tree = c->decoded.is_tree && chain_mode > 0;
+    static const bool tree_masks = !(std::getenv("RM_TREE_MASKS") && std::atoi(std::getenv("RM_TREE_MASKS")) == 0);  // A/B
+    const bool tree_units = tree && !chain && !c->decoded.has_extensions && !c->decoded.tree.empty() && tree_masks && lds;
+    const bool units = c->decoded.unit_mode == RM_UNITS_LATTICE && (chain || tree_units) && chain_mode >= 2 && c->decoded.n_leaves >= kPruneLeaves;
+    L.n_tree = units && tree_units ? (uint32_t)c->decoded.tree.size() : 0u;
+    if (L.n_tree != 0u) L.spill_depth += 1u;  // (map_scene_tree_masked spills at every push)
     L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (units ? 8u : 0u) | (tree ? 16u : 0u);
-    c->last_loop = (L.flags & 4u) ? (((L.flags & 8u) && lds) ? 2 : 1) : (tree && !c->decoded.has_extensions) ? 3 : 0;  // (the scalar-cache variant has no unit records at hand)
+    // (the scalar-cache variant has no unit records at hand)
+    c->last_loop = (L.flags & 4u) ? (((L.flags & 8u) && lds) ? 2 : 1) : (tree && !c->decoded.has_extensions) ? (L.n_tree != 0u ? 4 : 3) : 0;
     // programs that blend: a ray the plain miss tests cannot clear (every bound is inflated by the blend radius) gets the
     // program run on lower bounds of its leaves along the ray.  RM_BOUND_WALK=0 (diagnostics) keeps the plain tests only.
     static const bool bound_walk_on = !(std::getenv("RM_BOUND_WALK") && std::atoi(std::getenv("RM_BOUND_WALK")) == 0);
@@ -390,14 +397,14 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     const size_t cull_bytes = (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u;
     // structure-specialised kernel (values live in registers: no LDS spill stack)
     hipFunction_t spec_fn = lds ? specialised_kernel(c, WPT) : nullptr;
-    if (spec_fn) L.spill_depth = 0u;
+    if (spec_fn) { L.spill_depth = 0u; L.n_tree = 0u; }
     // the material evaluation of a tagged program borrows the spill area: (distance, index) pairs + saved positions
     // (a specialised kernel with the generated material walk keeps those pairs in registers too)
     if (L.n_mrec != 0u && !(spec_fn && c->spec && c->spec->material_walk))
         L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
     const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
-                         (lds ? (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord) : 0u) + kV5TailBytes +
+                         (lds ? (size_t)(L.n_rec + L.n_grp + L.n_tree) * sizeof(RmRecord) : 0u) + kV5TailBytes +
                          (L.n_mrec != 0u ? 1024u : 0u);
     if (shmem > 64u * 1024u) return fail(c, RM_ERR_TOO_LARGE, "program needs %zu bytes of LDS per tile", shmem);
     // pre-pass buffers: cost + work list per tile, {count, cursor} per frame
@@ -472,8 +479,8 @@ int launch_v5(rm_ctx* c, const RmLaunch& L, bool lds, uint32_t n_frames, hipStre
     const size_t launch_tiles = (size_t)((L.W + 7u) / 8u) * ((L.rows + 7u) / 8u) * n_frames;
     int wpt = c->waves_per_tile != 0 ? c->waves_per_tile : (launch_tiles <= 6000u ? 8 : 4);
     const size_t cull_bytes = L.n_rec <= 256u ? (size_t)L.n_cone * 16u + (size_t)L.n_slab * 48u : 0u;  // tables exist up to 256 records
-    const size_t prog_bytes = (size_t)(L.n_rec + L.n_grp) * sizeof(RmRecord);
-    const size_t depth = std::max<size_t>(L.spill_depth, L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
+    const size_t prog_bytes = (size_t)(L.n_rec + L.n_grp + c->decoded.tree.size()) * sizeof(RmRecord);  // (the tree table: at most 4 KB, when the interpreter uses it)
+    const size_t depth = std::max<size_t>(L.spill_depth + (c->decoded.tree.empty() ? 0u : 1u), L.n_mrec != 0u ? 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth : 0u);
     const size_t per_wave = rmk::V5_WAVE_DWORDS * 4u + depth * 256u;
     const size_t fixed = 4096u + cull_bytes + kV5TailBytes + (L.n_mrec != 0u ? 1024u : 0u);
     // A long program (rm_resize_command_buffer admits 64 KB of commands, ~2 700 leaves = 85 KB of records) does not fit
@@ -498,6 +505,7 @@ int launch(rm_ctx* c, const rm_uniforms* frames_dev, uint32_t n_frames, uint32_t
     L.prog = c->d_prog;
     L.n_rec = (uint32_t)c->decoded.rec.size();
     L.n_grp = (uint32_t)c->decoded.units.size();
+    L.n_tree = 0u;  // (set by launch_v5_w when the interpreter runs the masked tree loop)
     L.unit_mode = c->decoded.unit_mode;
     L.unit_kmax = c->decoded.unit_kmax;
     L.value_spill_depth = c->decoded.spill_depth;

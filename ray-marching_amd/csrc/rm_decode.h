@@ -41,11 +41,17 @@ struct RmDecoded {
     // (RM_OP_FASTCLASS): the interpreter kernels run such programs through map_scene_chain (rm_interp.h)
     bool is_chain = false;
     // Tree program: every record is one of the eight shapes of RM_OP_FASTCLASS (spheres, boxes, Union, Subtraction in any
-    // arrangement): the interpreter kernels run it through map_scene_tree.  With unit records (unit_mode RM_UNITS_LATTICE) a pushed
-    // leaf that starts the right operand of a Union / Subtraction also says how to step over that whole operand when none of
-    // its leaves is needed -- min(a, +inf) and max(a, -inf) leave a alone --: the unit record's p[4], as an integer,
-    // records | leaves << 16 | 1 << 24 (0: not such a leaf).
+    // arrangement): the interpreter kernels run it through map_scene_tree.
+    // tree: with unit records (unit_mode RM_UNITS_LATTICE) and at most 128 records, one entry per RECORD from which a wave turns
+    // its unit mask into the set of records it has to execute at all (rm_kernel_v5.h tree_keep; executed by
+    // map_scene_tree_masked).  L / R: the units (leaves) of the record's left / right operand, as 64-bit masks:
+    //   p[0], p[1]  L, low and high word: a leaf fused with its operator -- everything the accumulator holds when it is reached;
+    //               an operator record -- the operand it pops; a pushed leaf -- 0
+    //   p[2], p[3]  R: a leaf -- its own unit; an operator record -- the operand in the accumulator
+    //   p[4]        bits 0-1: 0 pushed leaf, 1 fused leaf, 2 operator record; bit 2: the operator is a Subtraction;
+    //               bits 8-13: the unit of L's FIRST leaf (always a pushed leaf)
     bool is_tree = false;
+    std::vector<RmRecord> tree;
     // The miss test of a ray can run the program on lower bounds (rm_kernel_v5.h "Miss test on lower bounds"): the program
     // blends with SmoothUnion, holds a Plane the tables cannot clear, or an Intersection (otherwise the plain tests are as
     // sharp), its leaves
@@ -363,29 +369,6 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
             }
             d.units.push_back(g);
         }
-        if (d.unit_mode == RM_UNITS_LATTICE) {  // how to step over a right operand, see RmDecoded::is_tree
-            for (size_t ui = 0; ui < us.size(); ui++) {
-                const size_t i = (size_t)us[ui].first;
-                uint32_t info = 0u;
-                if (RM_OP_MODE(d.rec[i].op) == RM_MODE_PUSH && (d.rec[i].op & RM_OP_SPILL)) {
-                    int depth = 1;  // counted from the accumulator that spilled
-                    uint32_t leaves = 0u;
-                    size_t j = i;
-                    bool plain = true;  // only leaves and operators inside (no transform, nothing unbounded)
-                    for (; j < d.rec.size(); j++) {
-                        const uint32_t kj = RM_OP_KIND(d.rec[j].op), mj = RM_OP_MODE(d.rec[j].op);
-                        if (kj == RM_KIND_POP) depth--;
-                        else if (rm_bounded_leaf(kj)) { leaves++; if (mj == RM_MODE_PUSH) depth++; }
-                        else plain = false;
-                        if (depth == 1) break;
-                    }
-                    if (j < d.rec.size() && plain && leaves <= 64u && j - i + 1u < 65536u &&
-                        (RM_OP_MODE(d.rec[j].op) == RM_MODE_UNION || RM_OP_MODE(d.rec[j].op) == RM_MODE_SUB))
-                        info = (uint32_t)(j - i + 1u) | (leaves << 16) | (1u << 24);
-                }
-                std::memcpy(&d.units[ui].p[4], &info, 4);
-            }
-        }
     }
     if (!d.rec.empty()) {
         const RmRecord& r0 = d.rec[0];
@@ -394,6 +377,42 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         for (size_t i = 1; d.is_chain && i < d.rec.size(); i++) d.is_chain = RM_OP_FASTCLASS(d.rec[i].op) >= 1u && RM_OP_FASTCLASS(d.rec[i].op) <= 4u;
         d.is_tree = true;
         for (const RmRecord& r : d.rec) d.is_tree = d.is_tree && RM_OP_FASTCLASS(r.op) != 0u;
+        if (d.is_tree && !d.is_chain && d.unit_mode == RM_UNITS_LATTICE && d.rec.size() <= 128u) {  // RmDecoded::tree
+            struct Operand { unsigned long long leaves; uint32_t first; };
+            std::vector<Operand> stack;
+            Operand acc{0ull, 0u};
+            bool ok = true;
+            for (const RmRecord& r : d.rec) {
+                const uint32_t cls = RM_OP_FASTCLASS(r.op), un = RM_OP_UNIT(r.op);
+                unsigned long long Lm = 0ull, Rm = 0ull;
+                uint32_t info = 0u;
+                if (cls <= 6u) {
+                    if (un == 0u) { ok = false; break; }  // (cannot be: every sphere and box of a lattice program is a unit)
+                    Rm = 1ull << (un - 1u);
+                    if (cls >= 5u) {  // pushed
+                        if (r.op & RM_OP_SPILL) stack.push_back(acc);
+                        acc = Operand{Rm, un - 1u};
+                    } else {
+                        Lm = acc.leaves;
+                        info = 1u | (cls >= 3u ? 4u : 0u) | (acc.first << 8);
+                        acc.leaves |= Rm;
+                    }
+                } else {
+                    if (stack.empty()) { ok = false; break; }
+                    const Operand a = stack.back();
+                    stack.pop_back();
+                    Lm = a.leaves; Rm = acc.leaves;
+                    info = 2u | (cls == 8u ? 4u : 0u) | (a.first << 8);
+                    acc = Operand{a.leaves | acc.leaves, a.first};
+                }
+                RmRecord t;
+                std::memset(&t, 0, sizeof t);
+                const uint32_t w[5] = {(uint32_t)Lm, (uint32_t)(Lm >> 32), (uint32_t)Rm, (uint32_t)(Rm >> 32), info};
+                std::memcpy(&t.p[0], w, sizeof w);
+                d.tree.push_back(t);
+            }
+            if (!ok || !stack.empty()) d.tree.clear();
+        }
     }
     for (double sv : slack) d.smooth_slack = sv > d.smooth_slack || sv != sv ? sv : d.smooth_slack;  // map_scene returns the top; be generous
     // (a Plane the tables would have to clear: they cannot; an Intersection: they ask a ray to clear BOTH operands where

@@ -76,11 +76,32 @@ enum : uint32_t { RM_CMD_MATERIAL = 300, RM_MAX_MATERIALS = 256 };
 enum : uint32_t { RM_UNIT_START = 0, RM_UNIT_UM = 1, RM_UNIT_SUB = 2, RM_UNIT_INTER = 3, RM_UNIT_OPAQUE = 4, RM_UNIT_LEAF = 5 };
 enum : uint32_t { RM_UNITS_NONE = 0, RM_UNITS_LATTICE = 1, RM_UNITS_BLEND = 2 };
 
+// Tree programs under the interpreter's masked loop (RmDecoded::tree, rm_kernel_v5.h tree_keep): what ONE record does given the
+// wave's unit mask `need` -- L, R: the units of its operands, info: RmDecoded::tree p[4].  Shared with the CPU model of the loop
+// (tests/cpp/tree_keep_model.cpp).
+#if defined(__HIPCC__)
+#define RM_HD __device__ __forceinline__
+#else
+#define RM_HD static inline
+#endif
+// a Subtraction whose left operand has no needed leaf while its right operand has one: forces rm_tree_forced_unit back into the mask
+RM_HD bool rm_tree_forces(unsigned long long L, unsigned long long R, uint32_t info, unsigned long long need) {
+    return (info & 4u) != 0u && (L & need) == 0ull && (R & need) != 0ull;
+}
+RM_HD uint32_t rm_tree_forced_unit(uint32_t info) { return (info >> 8) & 63u; }
+// with the forced units in `need`: is the record executed ...
+RM_HD bool rm_tree_keeps(unsigned long long L, unsigned long long R, uint32_t info, unsigned long long need) {
+    return (R & need) != 0ull && ((info & 3u) != 2u || (L & need) != 0ull);
+}
+// ... and does a fused leaf push its value because there is nothing to combine it with
+RM_HD bool rm_tree_pushes(unsigned long long L, uint32_t info, unsigned long long need) { return (info & 3u) == 1u && (L & need) == 0ull; }
+
 struct RmLaunch {
     const RmRecord* prog;      // decoded program, device memory
     uint32_t n_rec;            // == cmd_count of the reference program
     uint32_t n_grp;            // unit records that follow the n_rec program records in `prog` (wave-level culling: one bounded
                                // stand-in per unit, RmDecoded::units); staged in LDS with the program
+    uint32_t n_tree;           // 0, or n_rec: the per-record operand masks (RmDecoded::tree) follow the unit records; interpreter, masked tree loop
     uint32_t unit_mode;        // RM_UNITS_* (rm_units.h): 0 none, 1 lattice program (threshold rule), 2 blending chain
     float unit_kmax;           // the largest blend radius of a unit (the chain of blends never falls further below its smallest leaf)
     uint32_t spill_depth;      // LDS slots per lane this program needs: value stack, then 3 per transform level
@@ -88,7 +109,7 @@ struct RmLaunch {
     const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:
                                // programs with transforms (their miss tests use these instead of the parameters)
     uint32_t n_cull;           // entries of the miss-ray culling table (== n_rec when culling is on)
-    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 4: tree program (map_scene_tree); bit 3: ... with far pairs skipped (map_scene_chain_pruned); bit 5: miss test on lower bounds (RmDecoded::bound_walk); bits 8-14: diagnostics (RM_PRE_NEED_MAX)
+    uint32_t flags;            // bit 0: miss-ray culling enabled; bit 2: chain program (interpreter kernels: map_scene_chain); bit 4: tree program (map_scene_tree); bit 3: ... with the wave's unit mask (masked chain loop, map_scene_tree_masked); bit 5: miss test on lower bounds (RmDecoded::bound_walk); bits 8-14: diagnostics (RM_PRE_NEED_MAX)
     uint32_t n_cone, n_slab;   // v5 miss-test tables: spheres / (boxes + cylinders) of the program
     float smooth_slack;        // sum of k/4 over SmoothUnion operators: how far they can lower the tree value
     float scene_scale;         // 1 + max |centre|_1 + |size|_1 over the primitives (RmDecoded::scene_scale)

@@ -322,13 +322,8 @@ RM_DEV float map_scene_chain(const Prog& prog, uint32_t n_rec, float x, float y,
 // reference's node-graph editor can produce at all (csg/mod.rs:28-45) -- decoded into the eight record shapes of
 // RM_OP_FASTCLASS.  One dispatch per record, the popped operands in the wave's LDS spill column; same leaf functions, same
 // operators, same order as exec_command: the same bits.
-// MASKED: `need` is the wave's unit mask (rm_kernel_v5.h "Wave-level culling").  A leaf whose bit is clear is +inf: fused, its
-// record is a no-op; pushed, it pushes +inf -- unless it starts the right operand of a Union / Subtraction none of whose
-// leaves is needed: the whole operand is +inf then, min(a, +inf) and max(a, -inf) are a, and the loop steps over all its
-// records at once (`span`: the unit table's row 4, RmDecoded::is_tree).
-template <bool FAST, bool MASKED, class Prog>
-RM_DEV float map_scene_tree(const Prog& prog, uint32_t n_rec, float* spill, float x, float y, float z, unsigned long long need,
-                            const uint32_t* span, SqrtGuard& tiny) {
+template <bool FAST, class Prog>
+RM_DEV float map_scene_tree(const Prog& prog, uint32_t n_rec, float* spill, float x, float y, float z, SqrtGuard& tiny) {
     const float inf = __uint_as_float(0x7F800000u);
     float acc = inf;
     uint32_t sp = 0u, c = 0u;
@@ -336,42 +331,82 @@ RM_DEV float map_scene_tree(const Prog& prog, uint32_t n_rec, float* spill, floa
     float p0[7], p1[7];
     // the record at c waits in (opc, pc); the next one is fetched into (opn, pn) before c is executed.  true: the program is done
     auto step = [&](uint32_t& opc, float (&pc)[7], uint32_t& opn, float (&pn)[7]) -> bool {
-        for (;;) {
-            const uint32_t op = __builtin_amdgcn_readfirstlane(opc);
-            const uint32_t cls = RM_OP_FASTCLASS(op), un = RM_OP_UNIT(op);
-            const bool far = MASKED && un != 0u && ((need >> (un - 1u)) & 1ull) == 0ull;  // wave-uniform
-            if (MASKED && far && (cls == 5u || cls == 6u) && (op & RM_OP_SPILL)) {
-                const uint32_t info = span[un - 1u];  // wave-uniform address
-                const uint32_t leaves = (info >> 16) & 0xFFu;
-                const unsigned long long inside = (leaves >= 64u ? ~0ull : ((1ull << leaves) - 1ull)) << (un - 1u);
-                if ((info >> 24) != 0u && (need & inside) == 0ull) {  // the whole right operand is +inf
-                    c += info & 0xFFFFu;
-                    if (c >= n_rec) return true;
-                    prog.load(c, opc, pc);
-                    continue;
-                }
-            }
-            prog.load(c + 1u < n_rec ? c + 1u : c, opn, pn);
-            if (cls <= 4u) {  // (class 0 does not occur in a tree program)
-                if (!far) {
-                    const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny);
-                    acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
-                }
-            } else if (cls <= 6u) {
-                if (op & RM_OP_SPILL) { spill[sp * 64u] = acc; ++sp; }
-                acc = far ? inf : (cls == 5u ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny));
-            } else {
-                --sp;
-                const float a = spill[sp * 64u];
-                acc = cls == 7u ? vmin(a, acc) : vmax_negb(a, acc);
-            }
-            return ++c == n_rec;
+        const uint32_t op = __builtin_amdgcn_readfirstlane(opc);
+        const uint32_t cls = RM_OP_FASTCLASS(op);
+        prog.load(c + 1u < n_rec ? c + 1u : c, opn, pn);
+        if (cls <= 4u) {  // (class 0 does not occur in a tree program)
+            const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny);
+            acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
+        } else if (cls <= 6u) {
+            if (op & RM_OP_SPILL) { spill[sp * 64u] = acc; ++sp; }
+            acc = cls == 5u ? sdf_sphere_t<FAST>(x, y, z, pc, tiny) : sdf_box_t<FAST>(x, y, z, pc, tiny);
+        } else {
+            --sp;
+            const float a = spill[sp * 64u];
+            acc = cls == 7u ? vmin(a, acc) : vmax_negb(a, acc);
         }
+        return ++c == n_rec;
     };
     prog.load(0u, op0, p0);
     for (;;) {
         if (step(op0, p0, op1, p1)) break;
         if (step(op1, p1, op0, p0)) break;
+    }
+    return acc;
+}
+
+// The same with the wave's unit mask (rm_kernel_v5.h "Wave-level culling", lattice rule: a leaf whose bit is clear may be replaced by
+// +inf).  An operand none of whose leaves is needed is +inf as a whole -- min(a, +inf) = a, max(a, -(+inf)) = a: the operator that
+// would consume it is the identity on its other operand, and neither the operand's records nor the operator's need executing.
+// tree_keep (rm_kernel_v5.h) has turned the unit mask into the RECORDS that are left -- keep -- and this loop walks its set bits,
+// at most 128, fetching one record ahead: a handful of records of a tree of dozens.  What is left is again a well-formed postfix
+// program: every operand with a needed leaf leaves one value, every other none.  Every push spills the accumulator (the first
+// one an unused +inf: one slot more than map_scene_tree needs); a fused leaf whose left operand has gone (as_push) pushes.
+template <bool FAST, class Prog>
+RM_DEV float map_scene_tree_masked(const Prog& prog, float* spill, float x, float y, float z, unsigned long long keep0, unsigned long long keep1,
+                                   unsigned long long push0, unsigned long long push1, SqrtGuard& tiny) {
+    float acc = __uint_as_float(0x7F800000u);
+    uint32_t sp = 0u;
+    uint32_t opa, opb;
+    float pa[7], pb[7];
+    auto apply = [&](uint32_t c, uint32_t op, const float (&p)[7]) {
+        op = __builtin_amdgcn_readfirstlane(op);
+        const uint32_t cls = RM_OP_FASTCLASS(op);
+        if (cls <= 6u) {
+            const float b = (cls & 1u) ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);
+            const bool as_push = (((c < 64u ? push0 : push1) >> (c & 63u)) & 1ull) != 0ull;
+            if (cls >= 5u || as_push) {
+                spill[sp * 64u] = acc;
+                ++sp;
+                acc = b;
+            } else {
+                acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
+            }
+        } else {
+            --sp;
+            const float a = spill[sp * 64u];
+            acc = cls == 7u ? vmin(a, acc) : vmax_negb(a, acc);
+        }
+    };
+    unsigned long long m0 = keep0, m1 = keep1;
+    auto next = [&]() -> uint32_t {  // (the caller knows a bit is left)
+        uint32_t c;
+        if (m0 != 0ull) { c = (uint32_t)__builtin_ctzll(m0); m0 &= m0 - 1ull; }
+        else { c = 64u + (uint32_t)__builtin_ctzll(m1); m1 &= m1 - 1ull; }
+        return c;
+    };
+    if ((m0 | m1) == 0ull) return acc;
+    uint32_t ca = next(), cb = 0u;
+    prog.load(ca, opa, pa);
+    for (;;) {  // record ca waits in (opa, pa)
+        const bool more = (m0 | m1) != 0ull;
+        if (more) { cb = next(); prog.load(cb, opb, pb); }
+        apply(ca, opa, pa);
+        if (!more) break;
+        const bool more2 = (m0 | m1) != 0ull;
+        if (more2) { ca = next(); prog.load(ca, opa, pa); }
+        apply(cb, opb, pb);
+        if (!more2) break;
     }
     return acc;
 }

@@ -119,17 +119,20 @@ constexpr float kPruneAbs = 4.0e-6f;
 // Cost: ~50 vector instructions per evaluation for a lattice program, ~100 for a blending one, whatever the number of units.
 #define RM_DPP(old, src, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(src), (ctrl), 0xF, 0xF, false))
 // largest value over the wave, wave-uniform (all 64 lanes must be active; lanes without a value pass 0).  Four DPP steps
-// leave every row of 16 lanes with its maximum: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.
+// leave every row of 16 lanes with its maximum (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), two
+// row broadcasts carry it on to lane 63 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; a lane without a source
+// gets 0), one v_readlane fetches it.  (The first form read the four rows' maxima with four v_readlane and combined them with
+// three s_max_u32: instructions of the 4.3-cycle kind -- a CU has ONE scalar unit for its four SIMDs,
+// profiles/r03_ubench_scalar_issue_cycles.txt -- where a DPP step is an ordinary vector instruction.)
 RM_DEV uint32_t wave_max_u32(uint32_t v) {
     uint32_t t;
     t = RM_DPP(0u, v, 0xB1); v = t > v ? t : v;
     t = RM_DPP(0u, v, 0x4E); v = t > v ? t : v;
     t = RM_DPP(0u, v, 0x141); v = t > v ? t : v;
     t = RM_DPP(0u, v, 0x140); v = t > v ? t : v;
-    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
-    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
-    const uint32_t ab = a > b ? a : b, cd = c > d ? c : d;
-    return ab > cd ? ab : cd;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // minimum over the lanes BELOW this one (+inf for lane 0); all 64 lanes active.  row_shr:1,2,3, row_shr:4, row_shr:8 scan a row
 // of 16, row_bcast:15 and row_bcast:31 carry the rows' totals on (a lane without a source keeps +inf; min is idempotent, so
@@ -229,6 +232,65 @@ RM_DEV unsigned long long wave_cull_blend(const uint32_t* lunits, uint32_t n_uni
     const unsigned long long poison_m = (opaque_m | (__builtin_amdgcn_ballot_w64((is_sub || is_int) && !skip) & valid)) & from_r;
     const unsigned long long behind_poison = poison_m ? ~((2ull << __builtin_ctzll(poison_m)) - 1ull) : 0ull;  // (2 << 63 = 0: none)
     return valid & from_r & (~skip_m | behind_poison | (1ull << r));
+}
+// Tree programs under the interpreter (rm_interp.h map_scene_tree_masked): from the wave's unit mask to the RECORDS the wave has
+// to execute.  Lane r looks at records r and r + 64 (RmDecoded::tree, staged like the unit table: one row per field), L and R
+// being the units of the record's operands:
+//   a leaf is kept iff its unit is needed; an operator record iff both operands hold a needed leaf -- with one of them all +inf a
+//   Union or the right side of a Subtraction is the identity on the other: dropped, with the operand's records;
+//   a fused leaf whose left operand has gone (Union only, see below) pushes instead of combining: as_push;
+//   a Subtraction whose LEFT operand has gone while the right one has not is max(+inf, .) = +inf only in name -- nothing would
+//   push that +inf.  It FORCES the first leaf of its left operand back into the mask (evaluating a far leaf instead of replacing
+//   it is always allowed).  One pass suffices: the forced leaf lies in an operand that was entirely empty, so no other
+//   record's decision changes -- operators inside that operand still have an empty side, operators above it had a needed leaf on
+//   this side already (the right operand's).
+struct TreeKeep { unsigned long long keep0, keep1, push0, push1; };
+RM_DEV TreeKeep tree_keep(const uint32_t* ltree, uint32_t n_rec, unsigned long long need) {
+    const uint32_t lane = threadIdx.x & 63u;
+    TreeKeep k{0ull, 0ull, 0ull, 0ull};
+    const bool two = n_rec > 64u;  // wave-uniform
+    unsigned long long Lm[2], Rm[2];
+    uint32_t info[2];
+    bool in[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const uint32_t r = lane + 64u * (uint32_t)h;
+        in[h] = r < n_rec;
+        const uint32_t* t = ltree + (in[h] ? r : 0u);
+        if (h == 0 || two) {
+            Lm[h] = (unsigned long long)t[0] | ((unsigned long long)t[n_rec] << 32);
+            Rm[h] = (unsigned long long)t[2u * n_rec] | ((unsigned long long)t[3u * n_rec] << 32);
+            info[h] = t[4u * n_rec];
+        } else {
+            Lm[h] = Rm[h] = 0ull;
+            info[h] = 0u;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (h == 1 && !two) break;
+        unsigned long long fm = __builtin_amdgcn_ballot_w64(in[h] && rm_tree_forces(Lm[h], Rm[h], info[h], need));
+        while (fm != 0ull) {  // rare
+            const int l = __builtin_ctzll(fm);
+            fm &= fm - 1ull;
+            need |= 1ull << rm_tree_forced_unit((uint32_t)__builtin_amdgcn_readlane((int)info[h], l));
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        if (h == 1 && !two) break;
+        const bool keep = in[h] && rm_tree_keeps(Lm[h], Rm[h], info[h], need);
+        const unsigned long long km = __builtin_amdgcn_ballot_w64(keep), pm = __builtin_amdgcn_ballot_w64(keep && rm_tree_pushes(Lm[h], info[h], need));
+        if (h == 0) { k.keep0 = km; k.push0 = pm; } else { k.keep1 = km; k.push1 = pm; }
+    }
+    return k;
+}
+RM_DEV void stage_tree(uint32_t* ltree, const RmRecord* __restrict__ tree, uint32_t n_tree, uint32_t tid, uint32_t n_threads) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(tree);
+    for (uint32_t k = tid; k < 5u * n_tree; k += n_threads) {
+        const uint32_t f = k / n_tree, r = k - f * n_tree;
+        ltree[k] = src[8u * r + 1u + f];
+    }
 }
 #undef RM_DPP
 
@@ -653,7 +715,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
     float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
     uint32_t* lprog = reinterpret_cast<uint32_t*>(t_slab + 3u * L.n_slab);
-    uint32_t* s_next = lprog + (PROG_IN_LDS ? (L.n_rec + L.n_grp) * 8u : 0u);  // shared pool cursor
+    uint32_t* s_next = lprog + (PROG_IN_LDS ? (L.n_rec + L.n_grp + L.n_tree) * 8u : 0u);  // shared pool cursor
     uint32_t* s_tile = s_next + 1;                                     // work-list slot of the current tile
     uint32_t* s_veto = s_next + 2;
     float* s_off = reinterpret_cast<float*>(s_next + 4);               // [16][2] screen offsets of the AA samples (wgsl:47-53)
@@ -677,6 +739,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // program (generated code reads the records rotated by one dword: parameters first, lds_load4), then the unit table
         for (uint32_t k = tid; k < L.n_rec * 8u; k += 64u * WPT) lprog[SPEC ? ((k & ~7u) | ((k + 7u) & 7u)) : k] = src[k];
         stage_units(lprog + 8u * L.n_rec, L.prog + L.n_rec, L.n_grp, tid, 64u * WPT);  // (7 of a unit record's 8 dwords: it fits the same space)
+        if constexpr (!SPEC) stage_tree(lprog + 8u * (L.n_rec + L.n_grp), L.prog + L.n_rec + L.n_grp, L.n_tree, tid, 64u * WPT);
     }
     if (tid == 0u) *s_veto = 0u;
     if (tid < 16u) sample_offset(u, tid >> 2, tid & 3u, s_off[2u * tid], s_off[2u * tid + 1u]);  // two divisions per sample, once
@@ -739,19 +802,25 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         } else if (L.flags & 4u) {  // chain program (wave-uniform): the stack-free record loop
             const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
             const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;  // (the unit records are staged in LDS with the program)
+#ifdef RM_INTERP_STATS
+            n_eval += (uint32_t)__builtin_popcountll(masked ? need : (L.n_rec >= 64u ? ~0ull : (1ull << L.n_rec) - 1ull));
+#endif
             v[0] = map_scene_chain<true>(prog, L.n_rec, x, y, z, need, masked, tiny);
             if (tiny.any_bad()) v[0] = map_scene_chain<false>(prog, L.n_rec, x, y, z, need, masked, tiny);
         } else if (!EXT) {  // tree program -- reference node types in any arrangement, all a kernel without the extensions ever gets --:
                             // one dispatch per record
             const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;
-            if (masked) {
+            if (masked) {  // ... over the records the wave's unit mask leaves (L.n_tree != 0)
                 const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
-                const uint32_t* span = lunits + 4u * L.n_grp;  // row 4 of the unit table
-                v[0] = map_scene_tree<true, true>(prog, L.n_rec, spill, x, y, z, need, span, tiny);
-                if (tiny.any_bad()) v[0] = map_scene_tree<false, true>(prog, L.n_rec, spill, x, y, z, need, span, tiny);
+                const TreeKeep k = tree_keep(lunits + 8u * L.n_grp, L.n_rec, need);
+#ifdef RM_INTERP_STATS  // diagnostics build (tools/wave_stats.py --interp-stats): records executed, per wave
+                n_eval += (uint32_t)(__builtin_popcountll(k.keep0) + __builtin_popcountll(k.keep1));
+#endif
+                v[0] = map_scene_tree_masked<true>(prog, spill, x, y, z, k.keep0, k.keep1, k.push0, k.push1, tiny);
+                if (tiny.any_bad()) v[0] = map_scene_tree_masked<false>(prog, spill, x, y, z, k.keep0, k.keep1, k.push0, k.push1, tiny);
             } else {
-                v[0] = map_scene_tree<true, false>(prog, L.n_rec, spill, x, y, z, ~0ull, nullptr, tiny);
-                if (tiny.any_bad()) v[0] = map_scene_tree<false, false>(prog, L.n_rec, spill, x, y, z, ~0ull, nullptr, tiny);
+                v[0] = map_scene_tree<true>(prog, L.n_rec, spill, x, y, z, tiny);
+                if (tiny.any_bad()) v[0] = map_scene_tree<false>(prog, L.n_rec, spill, x, y, z, tiny);
             }
         } else if (PROG_IN_LDS && (L.flags & 8u)) {  // the general record loop; records of units the wave does not need are skipped
             const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
@@ -958,12 +1027,28 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             continue;
         }
 #endif
-        // ---- B. one map_scene evaluation: a march step of every live ray, or normal tap tap_t of every waiting hit ----
+        // ---- B. map_scene evaluations: march steps of the live rays, or the normal taps of the waiting hits ----
+        // An inner loop of its own: evaluation follows evaluation until something else is due -- a refill, a tap phase, the end
+        // of the tile's rays --, and that can only change when a ray finishes.  Section A's questions (who is idle, who is live,
+        // how many hits wait) are then asked once per finished ray instead of once per step: a dozen scalar instructions and a
+        // handful of branches less per march step, in a kernel whose scalar side is as busy as its vector side (a CU has one
+        // scalar unit for four SIMDs: 4.3 cycles per scalar instruction per SIMD, profiles/r03_ubench_scalar_issue_cycles.txt).
+        // The sequence of evaluations is the one the flat loop produced.
+        uint32_t n_idle = tapping ? 0u : (uint32_t)__popcll(__ballot(mode == M_EMPTY));  // wave-uniform: lanes waiting for a ray
+        for (;;) {
+        // (the interpreter kernels keep ONE copy of the evaluation for march steps and taps: their record loops are large, and the
+        // loop unswitched on `tapping` costs the lean kernel its registers)
+        bool tapping_i = tapping;
+        if constexpr (!SPEC) {
+            uint32_t t = tapping ? 1u : 0u;
+            asm volatile("" : "+v"(t));
+            tapping_i = __builtin_amdgcn_readfirstlane(t) != 0u;
+        }
         float ex, ey, ez, thr = inf_f;
         bool is_live;
         uint32_t sgx = 0u, sgy = 0u, sgz = 0u;
         const uint32_t he = hq_n + lane;  // this lane's hit-buffer entry in a tap phase (< V5_HQ for every lane)
-        if (tapping) {  // pos + k_t * eps (wgsl:138-141); k_t * eps = +-eps exactly
+        if (tapping_i) {  // pos + k_t * eps (wgsl:138-141); k_t * eps = +-eps exactly
             tap_signs(tap_t, sgx, sgy, sgz);
             ex = hq_v[he] + __uint_as_float(__float_as_uint(eps) ^ sgx);
             ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
@@ -986,7 +1071,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
         // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
         // issue priority: the chain runs at the lone-wave rate and the short rays fill in behind it.
-        if (!tapping) {
+        if (!tapping_i) {
             const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && itr >= (RM_PRIO_LONG_RAYS << 10)));
             if (old_rays != 0u) __builtin_amdgcn_s_setprio(3);
             else __builtin_amdgcn_s_setprio(0);
@@ -994,7 +1079,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 #endif
         const float sd = eval_scene(ex, ey, ez, thr, is_live, live_m);
 
-        if (tapping) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
+        if (tapping_i) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
             const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
             const float vy = __uint_as_float(__float_as_uint(sd) ^ sgy);
             const float vz = __uint_as_float(__float_as_uint(sd) ^ sgz);
@@ -1005,10 +1090,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             if (++tap_t == 4u && !tagged) {
                 if (is_live) res[hq_rid[he] & 1023u] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
                 tap_t = TAP_IDLE;
-            } else {
-                tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
+                break;
             }
-            continue;
+            tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
+            if (tap_t == 4u) break;  // (tagged program: the material phase follows)
+            continue;                // the next tap of the same hits
         }
 
         // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
@@ -1024,6 +1110,8 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
 #endif
         const unsigned long long miss_mask = esc_m | (go_m & __ballot(itr >= iter_limit));             // loop bound, wgsl:90
+        const unsigned long long done_m = hit_mask | miss_mask;
+        if (done_m == 0ull) continue;  // every live ray goes on: nothing section A asks about has changed
         const bool hit = is_live && sd < L.min_dist, miss = lane_of(miss_mask, lane);
         if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
             if (hit) {
@@ -1050,6 +1138,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 mode = M_EMPTY;
             }
             sq_n += n_miss;
+        }
+        // back to section A when it has something to do: no ray left marching, enough idle lanes for a refill (refill_min; when
+        // the pool is exhausted A retires them), or 64 hits waiting for their normals
+        n_idle += (uint32_t)__popcll(done_m);
+        if ((live_m & ~done_m) == 0ull || n_idle >= refill_min || hq_n >= 64u) break;
         }
     }
     if (sq_n != 0u) flush_misses();

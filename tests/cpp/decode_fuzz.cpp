@@ -77,6 +77,7 @@ static int check(const RmDecoded& d) {
         if (g.p[3] < g.p[4]) return 14;          // (NaN compares false: a leaf with a NaN size has bounds +inf / -inf)
         if (!(g.p[5] >= 0.0f) || g.p[5] > d.unit_kmax) return 15;
     }
+    if (!d.tree.empty() && (d.tree.size() != d.rec.size() || d.rec.size() > 128u || !d.is_tree || d.is_chain || d.unit_mode != RM_UNITS_LATTICE)) return 16;
     if (d.is_chain && d.spill_depth != 0u) return 9;
     if (d.bound_walk && (d.has_xforms || d.spill_depth > 1u)) return 10;
     if (d.max_depth > 32u) return 11;

@@ -27,3 +27,23 @@ def test_decoder_survives_random_and_damaged_programs(tmp_path):
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
     assert "decoder fuzz ok" in run.stdout
+
+
+def test_masked_tree_loop_equals_the_whole_program_with_the_unneeded_leaves_at_infinity(tmp_path):
+    """tests/cpp/tree_keep_model.cpp: the interpreter's masked tree loop (rm_kernel_v5.h tree_keep, rm_interp.h
+    map_scene_tree_masked) as a CPU model over the decoder's real per-record tables and the decision functions the kernel
+    itself uses (rm_device.h rm_tree_*): for random trees, masks and leaf values, the records a mask leaves give the value of
+    the whole program with the other leaves at +inf, bit for bit, on a stack one slot deeper than the program's own."""
+    cxx = os.environ.get("CXX", "g++")
+    if not shutil.which(cxx):
+        pytest.skip("no C++ compiler")
+    exe = tmp_path / "tree_keep_model"
+    build = subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                            "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include"),
+                            "-I", os.path.join(ROOT, "ray-marching_amd", "csrc"), "-o", str(exe),
+                            os.path.join(ROOT, "tests", "cpp", "tree_keep_model.cpp")], capture_output=True, text=True, timeout=300)
+    assert build.returncode == 0, build.stderr[-3000:]
+    run = subprocess.run([str(exe), "2000"], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "tree keep model ok" in run.stdout

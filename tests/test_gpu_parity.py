@@ -117,8 +117,8 @@ def test_interpreter_record_loops(res, oracle, kernel):
     """Which record loop the interpreter kernels take (RM_INFO_INTERPRETER_LOOP) and that each renders the oracle's image:
     chains "a op b op c ..." of 1..9 primitives -- the stack-free loop over the records the wave's unit mask names --
     seen from outside, from inside a primitive and from far away;
-    other arrangements of reference nodes (a right-deep tree, operators on sub-trees) the tree loop -- which steps over a whole
-    right operand when the wave needs none of its leaves --, extension node types the general loop."""
+    other arrangements of reference nodes (a right-deep tree, operators on sub-trees) the tree loop -- from a dozen leaves on over
+    the records that are left once operands without a needed leaf are dropped --, extension node types the general loop."""
     rng = np.random.default_rng(11)
     W, H = 56, 40
     lim = (0.01, 100.0, 96)
@@ -146,11 +146,13 @@ def test_interpreter_record_loops(res, oracle, kernel):
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
     assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
     assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == (2 if kernel == _ffi.RM_KERNEL_V5_LDS else 1)
-    for scene in (scenes.right_deep(5), scenes.g32_balanced()):
+    for scene, masked in ((scenes.right_deep(5), False), (scenes.g32_balanced(), kernel == _ffi.RM_KERNEL_V5_LDS)):
         cc, w, u = oracle_case(oracle, scene, W, H, None)
         setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
         assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
-        assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 3        # trees of reference nodes: one dispatch per record
+        # trees of reference nodes: one dispatch per record (3); a dozen leaves or more, unit records at hand: over the records
+        # the wave's unit mask leaves (4)
+        assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == (4 if masked else 3)
     # ... and anything with an extension node type the general loop
     cc, w, u = oracle_case(oracle, scenes.EXT_SCENES["ext_mix"](), W, H, None)
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
@@ -161,6 +163,41 @@ def test_interpreter_record_loops(res, oracle, kernel):
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=KERNEL_SPEC)
     res.draw(W, H)
     assert res.info(_ffi.RM_INFO_SPECIALIZED) == 1 and res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
+
+
+def test_masked_tree_loop_of_the_interpreter(res, oracle):
+    """Random trees of 12..48 spheres and boxes under Union / Subtraction -- balanced, left-deep, right-deep and mixed, with
+    Subtractions whose left operand is a whole sub-tree (a wave that needs only the subtracted leaves forces one of that
+    sub-tree's back: rm_kernel_v5.h tree_keep) -- through the interpreter's masked tree loop, from outside, from among the
+    primitives and from far away: the oracle's image, bit for bit."""
+    rng = np.random.default_rng(2024)
+    W, H = 64, 48
+    lim = (0.01, 100.0, 128)
+    res.resize_command_buffer(8192)
+    cams = [scenes.STILL_CAMERA_EVENTS, [(2, -30.0, 0.0)] * 4, [(2, 60.0, 0.0), (1, 200.0, 30.0)]]
+
+    def build(t, n, shape, sub):
+        if n == 1:
+            c = rng.uniform(-2.5, 2.5, 3)
+            return (t.sphere(tuple(c), float(rng.uniform(0.2, 0.8))) if rng.random() < 0.5 else
+                    t.box(tuple(c), tuple(rng.uniform(0.15, 0.6, 3))))
+        left = n // 2 if shape == 0 else n - 1 if shape == 1 else 1 if shape == 2 else int(rng.integers(1, n))
+        a, b = build(t, left, shape, sub), build(t, n - left, shape, sub)
+        return t.op(scenes.SUBTRACTION if rng.random() < sub else scenes.UNION, a, b)
+
+    for case in range(10):
+        t = scenes._Tab()
+        n = int(rng.integers(12, 49))
+        if case % 4 == 2:
+            n = min(n, 28)      # (right-deep: the reference's value stack holds 32)
+        root = build(t, n, case % 4, (0.0, 0.15, 0.35)[case % 3])
+        cc, w = oracle.serialize(t.nodes, root)
+        for events in cams:
+            u, *_ = oracle.orbit_uniforms((float(W), float(H)), events=events)
+            setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=_ffi.RM_KERNEL_V5_LDS)
+            assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+            assert res.info(_ffi.RM_INFO_SPECIALIZED) == 0
+            assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) in ((2, 4) if case % 4 == 1 else (4,)), (case, n)      # (left-deep: a chain)
 
 
 @pytest.mark.parametrize("kernel", KERNELS, ids=KERNEL_IDS)

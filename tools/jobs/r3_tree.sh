@@ -1,0 +1,21 @@
+#!/bin/bash
+# GPU-box job (round 3): the interpreter's masked tree loop -- parity tests first, then A/B timings.  usage: tools/jobs/r3_tree.sh OUTDIR
+out=$1; mkdir -p "$out"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_jit.py -x -q -m gpu > "$out/tests.log" 2>&1; echo "tests rc=$?" > "$out/status.txt"
+tail -3 "$out/tests.log"
+grep -q "tests rc=0" "$out/status.txt" || { tail -60 "$out/tests.log"; exit 1; }
+t() { label=$1; sc=$2; w=$3; h=$4; it=$5; shift 5
+  r=$(python3 tools/time_kernel.py --scene $sc --width $w --height $h --max-iter $it --steps 30 "$@" 2>>"$out/err.log" | head -1)
+  echo "$label | $sc ${w}x${h}/$it | $r" | tee -a "$out/times.txt"; }
+for round in 1 2; do
+  t "generated" g32_balanced 1920 1080 256
+  t "interpreter" g32 1920 1080 256 --specialize 0
+  t "interpreter" g8 1920 1080 128 --specialize 0
+  t "interpreter, masked tree loop" g32_balanced 1920 1080 256 --specialize 0
+  RM_TREE_MASKS=0 t "interpreter, tree loop" g32_balanced 1920 1080 256 --specialize 0
+  RM_HIP_SO=$PWD/build/variants/librm_hip_lean5.so t "interpreter, masked tree loop, 5 waves per SIMD allowed" g32_balanced 1920 1080 256 --specialize 0
+  RM_HIP_SO=$PWD/build/variants/librm_hip_lean5.so t "interpreter, 5 waves per SIMD allowed" g32 1920 1080 256 --specialize 0
+  t "interpreter, masked tree loop" g32_balanced 3840 2160 256 --specialize 0
+  RM_TREE_MASKS=0 t "interpreter, tree loop" g32_balanced 3840 2160 256 --specialize 0
+done
+cat "$out/status.txt"

@@ -47,8 +47,14 @@ def jit_kernel(scene, prune):
     cc, words = csg.serialize(csg.scene(scene))
     with tempfile.TemporaryDirectory() as d:
         os.environ["RM_JIT_DUMP_DIR"] = d
+        old_cache = os.environ.get("RM_JIT_CACHE_DIR")
+        os.environ["RM_JIT_CACHE_DIR"] = "off"       # (a kernel read from the disk cache is not dumped)
         rc, ms, nbytes, log = renderer.jit_compile(cc, words, prune=prune)
         del os.environ["RM_JIT_DUMP_DIR"]
+        if old_cache is None:
+            del os.environ["RM_JIT_CACHE_DIR"]
+        else:
+            os.environ["RM_JIT_CACHE_DIR"] = old_cache
         if rc != 0:
             return None
         co = [f for f in os.listdir(d) if f.endswith(".co")][0]

@@ -23,6 +23,8 @@ p.add_argument("--specialize", type=int, default=2)
 p.add_argument("--prune", action="store_true", help="pruned specialised kernel; with RM_JIT_PRUNE_STATS=1 in the environment the "
                "'refills' field becomes the number of leaves evaluated")
 p.add_argument("--refill-min", type=int, default=0)
+p.add_argument("--interp-stats", action="store_true", help="a library built with -DRM_INTERP_STATS (tools/ab_build.sh): the 'refills' field is the "
+               "number of records the interpreter's masked loops executed")
 p.add_argument("--leaves", type=int, default=16, help="primitives of the scene (for the evaluated-leaf ratio)")
 a = p.parse_args()
 res = renderer.RayMarchingResources(0)
@@ -66,6 +68,8 @@ if a.prune and os.environ.get("RM_JIT_PRUNE_STATS"):
         refills = refills / 64.0
     print("%s: %.2f per iteration = %.3f of %d (iterations include tap phases, which are not counted)" % (
         what, refills.sum() / max(1.0, float(iters.sum())), refills.sum() / max(1.0, float(iters.sum()) * per), per))
+if a.interp_stats:
+    print("records executed: %.2f per iteration (iterations include tap phases: one evaluation each)" % (refills.sum() / max(1.0, float(iters.sum()))))
 k = np.argsort(-end)[:8]
 for i in k:
     print("  late wave: slot %d tile %d start %.0f end %.0f dur %.0f iters %d live/iter %.1f" %
