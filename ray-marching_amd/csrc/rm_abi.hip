@@ -106,6 +106,7 @@ struct rm_ctx {
     uint64_t spec_gen = ~0ull;
     int spec_wpt = 0;
     int spec_pruned = 0;            // rmjit::PRUNE_* of the requested kernel
+    bool spec_stats = false;        // ... and whether it keeps the counters of RM_OPT_WAVE_STATS
     bool last_specialized = false;  // the last march launch ran a specialised kernel
     int last_loop = 0;              // RM_INFO_INTERPRETER_LOOP of the last march launch
     // stream-ordered uploads (program records, bounds, batch uniforms): four pinned staging buffers, see upload()
@@ -269,11 +270,13 @@ int prune_kind(const RmDecoded& d, int option) {
 // launches the interpreter kernel.  Never an error.
 hipFunction_t specialised_kernel(rm_ctx* c, int wpt) {
     if (!c->specialize || !rmjit::can_specialise(c->decoded.rec)) return nullptr;
-    if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt) {
+    if (c->spec_gen != c->prog_gen || c->spec_wpt != wpt || c->spec_stats != c->wave_stats) {
         // same structure as before (parameters moved): the key lookup finds the same entry
         const int prune = prune_kind(c->decoded, c->prune);
-        c->spec = rmjit::Cache::get().request(c->decoded.rec, c->decoded.mrec, wpt, prune);
+        // (the per-wave counters of RM_OPT_WAVE_STATS are compiled into a kernel of their own: the default one does without)
+        c->spec = rmjit::Cache::get().request(c->decoded.rec, c->decoded.mrec, wpt, prune | (c->wave_stats ? rmjit::KERNEL_WITH_STATS : 0));
         c->spec_pruned = prune;
+        c->spec_stats = c->wave_stats;
         c->spec_gen = c->prog_gen;
         c->spec_wpt = wpt;
     }

@@ -132,6 +132,9 @@ inline int jit_knob(const char* name, int dflt) {
 // mask wave-level culling computes (threshold rule), 2 a program that blends whose top-level chain's units do (rm_units.h,
 // rm_kernel_v5.h "Wave-level culling")
 enum : int { PRUNE_NONE = 0, PRUNE_LATTICE = 1, PRUNE_BLEND = 2 };
+// ... | KERNEL_WITH_STATS: the kernel keeps the per-wave counters of RM_OPT_WAVE_STATS (iterations, live lanes).  A kernel without
+// them -- the default -- saves five scalar instructions per march step (rm_kernel_v5.h, RM_NO_WAVE_STATS)
+enum : int { KERNEL_WITH_STATS = 0x100, PRUNE_KIND_MASK = 0xFF };
 
 // Straight-line code for `rec`, mirroring exec_command (rm_interp.h) record by record with the value stack resolved at
 // generation time: the accumulator and every spilled value become named values, no opcode decode, no loop; parameters are
@@ -303,6 +306,36 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
         return true;
     };
 
+    // GROUPS of units: up to four consecutive units that each take the accumulator to its next value (a leaf fused with its
+    // operator, "leaf; SmoothUnion") sit behind ONE more test -- is any of them needed -- on a 32-bit word of the mask that the
+    // tests inside then share.  The rays of a wave are near one or two primitives, so most groups are skipped whole: two scalar
+    // instructions and a branch instead of eight and four, in kernels whose scalar side is their busiest (rm_kernel_v5.h,
+    // profiles/r03_ubench_scalar_issue_cycles.txt).  group_first[u]: units in the group that starts at unit u (0: none starts there).
+    std::vector<int> group_first(units.size(), 0);
+    if (jit_knob("RM_JIT_UNIT_GROUPS", 1) != 0) {
+        auto flows = [&](size_t u) {  // the unit consumes the accumulator and leaves the next one, whatever happens inside
+            const RmUnit& q = units[u];
+            if (q.kind == RM_UNIT_OPAQUE || q.leaf < 0) return false;
+            const uint32_t m = q.k_rec >= 0 ? (uint32_t)RM_MODE_SMOOTH : RM_OP_MODE(rec[(size_t)q.first].op);
+            if (m == RM_MODE_PUSH || (m == RM_MODE_INTER && q.kind == RM_UNIT_LEAF)) return false;  // (skipped, these are +inf)
+            return true;
+        };
+        for (size_t u = 0; u < units.size();) {
+            if (!flows(u)) { u++; continue; }
+            size_t e = u;  // the run [u, e] of consecutive units, consecutive in the records as well
+            while (e + 1 < units.size() && flows(e + 1) && units[e + 1].first == units[e].last + 1) e++;
+            for (size_t g = u; g <= e;) {
+                size_t n = e - g + 1 < 4 ? e - g + 1 : 4;
+                if (n == 4 && e - g + 1 == 5) n = 3;           // (3 + 2 rather than 4 + 1)
+                if ((g >> 5) != ((g + n - 1) >> 5)) n = 32 - (g & 31);  // a group stays within one word of the mask
+                if (n >= 2) group_first[g] = (int)n;
+                g += n;
+            }
+            u = e + 1;
+        }
+    }
+    int group_left = 0, group_value = -1;  // units still to come in the open group; the value that leaves it
+
     for (size_t i = 0; i < rec.size();) {
         const int ui = unit_at[i];
         if (ui < 0) {
@@ -313,6 +346,25 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
         const RmUnit& u = units[(size_t)ui];
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
         const int c = pos.back();
+        if (group_left == 0 && group_first[(size_t)ui] != 0) {  // a group starts: its value is the accumulator unless something inside is needed
+            if (stack.empty()) return false;
+            group_left = group_first[(size_t)ui];
+            group_value = nv++;
+            for (int t = 0; t < T; t++) { std::snprintf(line, sizeof line, "    float %s = %s;\n", V(group_value, t).c_str(), V(stack.back(), t).c_str()); s += line; }
+            uint32_t mask = 0u;
+            for (int k = 0; k < group_left; k++) mask |= 1u << ((ui + k) & 31);
+            std::snprintf(line, sizeof line, "    { const uint32_t wg = unit_word(need, %du);\n    if ((wg & 0x%xu) != 0u) {\n", ui, mask);
+            s += line;
+        }
+        char guard[64];
+        if (group_left != 0) std::snprintf(guard, sizeof guard, "unit_in_word(wg, %du)", ui);
+        else std::snprintf(guard, sizeof guard, "unit_needed(need, %du)", ui);
+        auto close_group = [&]() {  // after the unit's code: the last unit of a group hands its value out
+            if (group_left == 0 || --group_left != 0) return;
+            for (int t = 0; t < T; t++) { std::snprintf(line, sizeof line, "        %s = %s;\n", V(group_value, t).c_str(), V(stack.back(), t).c_str()); s += line; }
+            s += "    } }\n";
+            stack.back() = group_value;
+        };
         if (u.kind == RM_UNIT_OPAQUE) {
             // an opaque stretch of the chain: from the accumulator to its next value; evaluated unless it is dead
             if (stack.empty()) return false;
@@ -345,7 +397,7 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
             else std::snprintf(line, sizeof line, "    float %s = %s;\n", V(w, t).c_str(), V(a, t).c_str());
             s += line;
         }
-        std::snprintf(line, sizeof line, "    if (unit_needed(need, %du)) {%s\n", ui, counted);
+        std::snprintf(line, sizeof line, "    if (%s) {%s\n", guard, counted);
         s += line;
         const unsigned off = (unsigned)i * 8u;
         if (with_smooth) {
@@ -375,9 +427,10 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
         s += "    }\n";
         stack.push_back(w);
         after_leaf(false);
+        close_group();
         i = (size_t)u.last + 1u;
     }
-    if (stack.empty()) return false;
+    if (stack.empty() || group_left != 0) return false;
     if (T == 1) {
         std::snprintf(line, sizeof line, "    return %s;\n}\n}  // namespace rmk\n", V(stack.back(), 0).c_str());
         s += line;
@@ -531,6 +584,8 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
 inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune_kind, std::string* out,
                             bool* walk_generated = nullptr) {
     const bool materials = !mrec.empty();
+    const bool with_stats = (prune_kind & KERNEL_WITH_STATS) != 0;
+    prune_kind &= PRUNE_KIND_MASK;
     std::string body, taps, walk;
     if (!generate_scene_code(rec, prune_kind, 1, &body)) return false;
     const bool walk_spec = materials && jit_knob("RM_JIT_MATERIAL_WALK", 1) != 0 && mrec.size() <= kMaxRecords && generate_material_walk(mrec, &walk);
@@ -552,6 +607,8 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     if (taps4) s += "#define RM_JIT_TAPS4 1\n";
     if (walk_spec) s += "#define RM_JIT_MATERIAL_WALK 1\n";
     if (structure_allows_bound_walk(rec)) s += "#define RM_JIT_BOUND_WALK 1\n";
+    if (const char* f = std::getenv("RM_JIT_UNIT_TEST")) s += "#define RM_UNIT_TEST_FORM " + std::to_string(std::atoi(f)) + "\n";  // A/B: unit_needed
+    if (!with_stats) s += "#define RM_NO_WAVE_STATS 1\n";
     if (const char* pr = std::getenv("RM_JIT_PRIO_LONG_RAYS")) {  // experiment knob
         s += "#define RM_PRIO_LONG_RAYS ";
         s += std::to_string(std::atoi(pr));
@@ -761,11 +818,12 @@ public:
         // A/B knobs of the generator as the environment holds them now (so that a process may compare two settings)
         static const char* const knobs[] = {"RM_JIT_GUARD_FENCE", "RM_JIT_MATERIAL_WALK",
                                             "RM_JIT_PRIO_LONG_RAYS", "RM_JIT_PRUNE_STATS", "RM_JIT_SCHED_BARRIER", "RM_JIT_SCHED_BARRIER_TAPS",
-                                            "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU"};
+                                            "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU", "RM_JIT_UNIT_TEST", "RM_JIT_UNIT_GROUPS"};
         std::string knob_key;
         for (const char* name : knobs)
             if (const char* v = std::getenv(name)) knob_key += std::string("|") + name + "=" + v;
-        const std::string key = std::to_string(wpt) + (prune == PRUNE_LATTICE ? "p" : prune == PRUNE_BLEND ? "b" : "") + ":" + structure_key(rec) +
+        const std::string key = std::to_string(wpt) + ((prune & PRUNE_KIND_MASK) == PRUNE_LATTICE ? "p" : (prune & PRUNE_KIND_MASK) == PRUNE_BLEND ? "b" : "") +
+                                ((prune & KERNEL_WITH_STATS) ? "s" : "") + ":" + structure_key(rec) +
                                 (mrec.empty() ? "" : "|m:" + structure_key(mrec)) + knob_key;
         std::unique_lock<std::mutex> lk(m_);
         auto it = entries_.find(key);

@@ -308,9 +308,26 @@ __global__ __launch_bounds__(64) void rm_selftest_wave_kernel(const float* in, f
 // whole evaluation -- 30 more scalar registers spilled, which costs the vector register that decides between 6 and 5 waves
 // per SIMD.  With the asm each test is born where it is used: s_bitcmp1_b64 + s_cbranch_scc.
 RM_DEV bool unit_needed(unsigned long long need, uint32_t u) {
+#if defined(RM_UNIT_TEST_FORM) && RM_UNIT_TEST_FORM == 2  // A/B (RM_JIT_UNIT_TEST): the plain test
+    return ((need >> u) & 1ull) != 0ull;
+#elif defined(RM_UNIT_TEST_FORM) && RM_UNIT_TEST_FORM == 0  // A/B: the whole mask through the asm (s_mov_b64 + s_and_b32 + s_cmp_eq_u64)
     asm volatile("" : "+s"(need));
     return ((need >> u) & 1ull) != 0ull;
+#else  // the half of the mask that holds the bit: s_mov_b32 + s_bitcmp1_b32
+    uint32_t w = (uint32_t)(need >> (u & 32u));
+    asm volatile("" : "+s"(w));
+    return ((w >> (u & 31u)) & 1u) != 0u;
+#endif
 }
+
+// A group of units behind one test (rm_jit.h): the 32-bit word of the mask that holds unit u, through the asm once for the group;
+// the tests inside the group read it as it is (s_bitcmp1_b32)
+RM_DEV uint32_t unit_word(unsigned long long need, uint32_t u) {
+    uint32_t w = (uint32_t)(need >> (u & 32u));
+    asm volatile("" : "+s"(w));
+    return w;
+}
+RM_DEV bool unit_in_word(uint32_t w, uint32_t u) { return ((w >> (u & 31u)) & 1u) != 0u; }
 
 typedef float lds_f4 __attribute__((ext_vector_type(4)));
 typedef float lds_f2 __attribute__((ext_vector_type(2)));
@@ -848,6 +865,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const float inf_f = __uint_as_float(0x7F800000u);
 
     const unsigned long long t_start = L.stats ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    // (diagnostics, RM_OPT_WAVE_STATS; a generated kernel keeps them only when it was compiled for that: RM_NO_WAVE_STATS, rm_jit.h)
     uint32_t n_iter = 0u, n_live = 0u, n_prod = 0u, n_tiles_done = 0u;
 
   for (;;) {  // ---- next tile of the work list ----
@@ -1008,8 +1026,10 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             const unsigned long long need4 = units_needed(cx, cy, cz, thr_c, 3.5e-4f, live4, live4_m);
             map_scene_taps<true>(lprog_v, cx, cy, cz, need4, live4_m, tiny, f);
             if (tiny.any_bad()) map_scene_taps<false>(lprog_v, cx, cy, cz, need4, live4_m, tiny, f);
+#ifndef RM_NO_WAVE_STATS
             n_iter++;
             n_live += (uint32_t)__popcll(live4_m);
+#endif
             // n = ((k0 f0 + k1 f1) + k2 f2) + k3 f3, k = (+,-,-), (-,-,+), (-,+,-), (+,+,+); products with +-1 are exact
             const float nx = ((f[0] + -f[1]) + -f[2]) + f[3];
             const float ny = ((-f[0] + -f[1]) + f[2]) + f[3];
@@ -1064,9 +1084,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
             is_live = mode == M_MARCH;
             thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
         }
-        n_iter++;
         const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
+#ifndef RM_NO_WAVE_STATS
+        n_iter++;
         n_live += (uint32_t)__popcll(live_m);
+#endif
 #ifdef RM_PRIO_LONG_RAYS
         // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
         // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get

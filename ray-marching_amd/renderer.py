@@ -223,8 +223,21 @@ def program_info(cmd_count, words):
     return dict(zip(PROGRAM_FACTS, [int(v) for v in out]))
 
 
-def jit_source(cmd_count, words, waves_per_tile=4, prune=False):
-    """rm_jit_source: the HIP source the structure specialiser generates for a command stream (no GPU needed)."""
+def jit_source(cmd_count, words, waves_per_tile=4, prune=False, env=None):
+    """rm_jit_source: the HIP source the structure specialiser generates for a command stream (no GPU needed).
+    env: A/B knobs of the generator (RM_JIT_*), set in the process environment for this call only."""
+    if env:
+        import os
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            return jit_source(cmd_count, words, waves_per_tile, prune)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     w = np.ascontiguousarray(np.asarray(words, dtype=np.uint32))
     ptr = w.ctypes.data_as(C.POINTER(C.c_uint32)) if w.size else None
     L = _ffi.hip_lib()

@@ -45,23 +45,33 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "if (unit_needed(need, 0u)) {",
         "v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);",      # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
         "}",
+        # up to four consecutive units that take the accumulator to its next value sit behind one more test on a word of the mask
+        # -- is ANY of them needed --, which the tests inside share: most groups are skipped whole (rm_jit.h "GROUPS of units")
         "float v1 = v0;",
-        "if (unit_needed(need, 1u)) {",
-        "v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
-        "}",
-        "float v2 = v1;",
-        "if (unit_needed(need, 2u)) {",
-        # a SUBTRACTED leaf: evaluated only if some live lane is inside it, or inside the accumulated solid (max(acc, -v) = acc else)
-        "const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
-        "if (spec_sub_sphere_near(live, lp + 16, a, v1)) v2 = vmax_negb(v1, spec_sphere_v<FAST>(lp + 16, a, tiny));",
+        "{ const uint32_t wg = unit_word(need, 1u);",
+        "if ((wg & 0xeu) != 0u) {",
+        "float v2 = v0;",
+        "if (unit_in_word(wg, 1u)) {",
+        "v2 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
         "}",
         "float v3 = v2;",
-        "if (unit_needed(need, 3u)) {",
-        "v3 = vmin(v2, spec_box<FAST>(lp + 24, x0, y0, z0, tiny));",
+        "if (unit_in_word(wg, 2u)) {",
+        # a SUBTRACTED leaf: evaluated only if some live lane is inside it, or inside the accumulated solid (max(acc, -v) = acc else)
+        "const float a = spec_sphere_a(lp + 16, x0, y0, z0);",
+        "if (spec_sub_sphere_near(live, lp + 16, a, v2)) v3 = vmax_negb(v2, spec_sphere_v<FAST>(lp + 16, a, tiny));",
+        "}",
+        "float v4 = v3;",
+        "if (unit_in_word(wg, 3u)) {",
+        "v4 = vmin(v3, spec_box<FAST>(lp + 24, x0, y0, z0, tiny));",
         "}",
         "__builtin_amdgcn_sched_barrier(0);",
-        "return v3;",
+        "v1 = v4;",
+        "} }",
+        "return v1;",
     ]
+    ungrouped = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True, env={"RM_JIT_UNIT_GROUPS": "0"}))]
+    assert ungrouped[6:10] == ["float v1 = v0;", "if (unit_needed(need, 1u)) {", "v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));", "}"]
+    assert ungrouped[-2:] == ["__builtin_amdgcn_sched_barrier(0);", "return v3;"]
 
 
 def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
@@ -97,7 +107,20 @@ def evaluate_generated(body, nodes_params, pos, prune_all_far=None):
         if m:
             env[m.group(1)] = env[m.group(2)]
             continue
-        m = re.match(r"if \(unit_needed\(need, \d+u\)\) \{$", line)
+        if line.startswith("{ const uint32_t wg = unit_word(need,"):      # a group of units: skipped whole when every unit in it is far
+            assert re.match(r"if \(\(wg & 0x[0-9a-f]+u\) != 0u\) \{$", lines[i]), lines[i]
+            end = lines.index("} }", i)
+            inside = " ".join(lines[i + 1:end])
+            vals = [leaf(k, off) for k, off in re.findall(r"spec_(sphere|box)(?:_a|<FAST>)\(lp \+ (\d+),", inside)]
+            i = end + 1 if (prune_all_far and all(prune_all_far(v) for v in vals)) else i + 1
+            continue
+        if line == "} }":
+            continue
+        m = re.match(r"(v\d+) = (v\d+);$", line)
+        if m:             # the value that leaves a group
+            env[m.group(1)] = env[m.group(2)]
+            continue
+        m = re.match(r"if \((?:unit_needed\(need|unit_in_word\(wg), \d+u\)\) \{$", line)
         if m:             # one unit = one leaf: find its value, then decide whether the lane skips it
             block = []
             while lines[i] != "}":
