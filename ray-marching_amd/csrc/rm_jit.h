@@ -619,8 +619,14 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     if (taps4) s += taps;
     if (walk_spec) s += walk;
     char line[512];
-    if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) {  // experiment knob: cap the VGPR budget
-        std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", std::atoi(w), std::atoi(w));
+    // The kernel of a blending chain needs 86 vector registers (the mask's prefix scans on top of the four-tap function): 5 waves per
+    // SIMD.  Capped at 80 it spills nine of them and is 5 % FASTER (config 3 at 4K: 3.44 -> 3.27 ms); every other kind of kernel that
+    // sits above 80 loses by the same cap (balanced tree +7 %, materials +3 %, transforms +1 %: profiles/r03_refill_threshold_and_forced_occupancy.txt).
+    // RM_JIT_WAVES_PER_EU (A/B): n forces n waves per SIMD for every kernel, 0 none.
+    int waves = prune_kind == PRUNE_BLEND ? 6 : 0;
+    if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) waves = std::atoi(w);
+    if (waves > 0) {
+        std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", waves, waves);
         s += line;
     }
     std::snprintf(line, sizeof line,
