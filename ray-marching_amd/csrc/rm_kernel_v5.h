@@ -448,7 +448,7 @@ RM_DEV void spec_smooth_union4(LdsF r, const float (&a)[4], const float (&b)[4],
 constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
 constexpr uint32_t V5_SQ = 64u;   // miss buffer entries per wave
 constexpr uint32_t V5_HQ = 128u;  // hit buffer entries per wave (64 are taken whenever 64 are waiting)
-constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 3u * 64u;
+constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 3u * 64u + 16u;  // (+ 16: the screen coordinates of the tile's 8 columns and 8 rows)
 
 // Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
 // decoder stores each primitive's slot within its kind in RmRecord::p[6]):
@@ -727,6 +727,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     uint32_t* hq_rid = sq_rid + 4u * V5_SQ;                            // hits waiting for their normal: id, position
     float* hq_v = reinterpret_cast<float*>(hq_rid + V5_HQ);            // [3][V5_HQ]
     float* tn = hq_v + 3u * V5_HQ;                                     // [3][64] partial normals of the running tap phase
+    float* wxy = tn + 3u * 64u;                                        // [16] pt_screen.x of the tile's 8 columns, .y of its 8 rows (wgsl:41-43)
     uint32_t* after = smem + POOL + WPT * V5_WAVE_DWORDS;
     float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
@@ -882,10 +883,16 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     n_tiles_done++;
     const unsigned long long tile_t0 = work.measured ? __builtin_amdgcn_s_memrealtime() : 0ull;
 
-    // Ray r of the pool: pixel r & 63 (== this lane in a produce round), AA sample r >> 6.
-    const uint32_t tx = tile_x * 8u + (lane & 7u), ty = tile_y * 8u + (lane >> 3);
-    const float my_sx = screen_x(tx < L.W ? tx : L.W - 1u, L.W);                                   // edge tiles clamp
-    const float my_sy = screen_y(rm_global_row(L, ty < L.rows ? ty : L.rows - 1u), L.H);
+    // Ray r of the pool: pixel r & 63, AA sample r >> 6 (the resolve step reads res[] that way).  A produce round makes the 64
+    // rays of one BATCH: the sixteen samples of a 2x2 block of pixels (lane: sample lane >> 2, pixel lane & 3 of the block) --
+    // rays that stay within two pixels of each other march alike (they finish together: fewer idle lanes) and lie in a small
+    // ball (wave-level culling tests the units against that ball).  Round 2's batch was one sample of all 64 pixels.
+    if (lane < 16u) {
+        const uint32_t k = lane & 7u, tx = tile_x * 8u + k, ty = tile_y * 8u + k;
+        wxy[lane] = lane < 8u ? screen_x(tx < L.W ? tx : L.W - 1u, L.W)                                // edge tiles clamp
+                              : screen_y(rm_global_row(L, ty < L.rows ? ty : L.rows - 1u), L.H);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 
     // lane state of a marching ray: evaluation point = ro + d * sc
     float dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f;
@@ -925,21 +932,28 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         base = __builtin_amdgcn_readfirstlane(base);
                         if (base >= POOL) { pool_open = false; continue; }
                         n_prod++;
-                        const uint32_t r = base + lane, s = base >> 6;
+                        // batch -> block of the 4x4 blocks of the tile: the corners first, then the centre (see test_rays below)
+                        const uint32_t blk = (uint32_t)(0xEDB87421A965FC30ull >> (4u * (base >> 6))) & 15u;
+                        // (the lane's part of these is recomputed per round: hoisted out of the loop it would sit in registers through
+                        // the four-tap function, whose pressure decides between 6 and 5 waves per SIMD)
+                        uint32_t ln = lane;
+                        asm volatile("" : "+v"(ln));
+                        const uint32_t bpx = 2u * (blk & 3u) + (ln & 1u), bpy = 2u * (blk >> 2) + ((ln >> 1) & 1u), s = ln >> 2;
+                        const uint32_t r = s * 64u + bpy * 8u + bpx;
                         float gx, gy, gz;
-                        gen_ray_at(u.inv_proj, u.inv_view, ro, my_sx, my_sy, s_off[2u * s], s_off[2u * s + 1u], gx, gy, gz);
+                        gen_ray_at(u.inv_proj, u.inv_view, ro, wxy[bpx], wxy[8u + bpy], s_off[2u * s], s_off[2u * s + 1u], gx, gy, gz);
                         const bool finite_d = __builtin_fabsf(gx) < inf_f && __builtin_fabsf(gy) < inf_f && __builtin_fabsf(gz) < inf_f;
                         // The miss tests are optional (a ray they do not clear is marched and ends as the same miss): in a tile
                         // the scene covers completely they clear nothing -- 92 % of the rays that reach this kernel are marched --
-                        // so once a batch of 64 rays (one sample of every pixel of the tile) went through without a single ray
-                        // cleared, the rest of the tile's batches skip them.
-                        const bool test_rays = (L.flags & 1u) != 0u && __builtin_amdgcn_readfirstlane(s_next[3]) == 0u;
+                        // so once the batches of the tile's four CORNER blocks (the first four of the pool) went through without
+                        // a single ray cleared, the rest of the tile's batches skip them.
+                        const bool test_rays = (L.flags & 1u) != 0u && __builtin_amdgcn_readfirstlane(s_next[3]) < 4u;
                         bool culled = L.max_iter == 0u || (start == START_DONE && finite_d) || (test_rays && ray_misses_scene_v5(cullt, gx, gy, gz));
 #if !defined(RM_JIT_TU) || defined(RM_JIT_BOUND_WALK)  // a generated kernel carries it only if its program's structure can use it
                         if (test_rays && (L.flags & 32u) && (*s_veto & 1u) == 0u && bound_scale < 1.0e12f && __ballot(!culled) != 0ull)  // "Miss test on lower bounds"
                             culled = culled || ray_misses_by_bounds_v5<false>(load_record, L.n_rec, ro, gx, gy, gz, L.min_dist, bound_scale);
 #endif
-                        if (test_rays && __ballot(culled) == 0ull && lane == 0u) s_next[3] = 1u;
+                        if (test_rays && base < 256u && __ballot(culled) == 0ull && lane == 0u) atomicAdd(&s_next[3], 1u);
                         if (culled) res[r] = miss_code(ro, gx, gy, gz);  // never marched: wgsl:117-130 only
                         const unsigned long long keep = __ballot(!culled);
                         if (!culled) {
