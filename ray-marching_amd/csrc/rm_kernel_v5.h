@@ -101,9 +101,10 @@ constexpr float kPruneAbs = 4.0e-6f;
 //   p*   the position of the first live lane,  rho >= max over live lanes |p_l - p*|   (one wave reduction)
 //   unit u with centre c, outer radius R, inner radius r_in:  for every live lane
 //        L_u = |p* - c| - R - rho  <=  value_u(p_l)  <=  |p* - c| + rho - r_in = H_u      (triangle inequality)
-// LATTICE programs (threshold rule above): T >= max over live lanes thr_l (a second reduction); unit u is needed unless
-//   L_u > T.  A CPU simulation of the metric frame (tools/sim/wave_cull_sim.py) has this evaluate 4.5 of 16 leaves per
-//   step where the per-lane pair tests evaluate 5.5 and a per-lane, per-leaf test 4.2.
+// LATTICE programs (threshold rule above): unit u is far for lane l when |p* - c| - R - |p_l - p*| > thr_l; for the whole wave
+//   when |p* - c| - R > S = max over live lanes (|p_l - p*| + thr_l) -- one reduction (the first form took rho and T = max thr_l
+//   separately: L_u > T).  A CPU simulation of the metric frame (tools/sim/wave_cull_sim.py) has the rho + T form evaluate 4.5 of
+//   16 leaves per step where the per-lane pair tests evaluate 5.5 and a per-lane, per-leaf test 4.2.
 // Programs that BLEND, top-level chain (rm_units.h).  With a_hi(u) = min over the Union / SmoothUnion units j < u of H_j
 //   (the accumulator a unit meets is at most the smallest leaf blended in so far) and a_lo(u) = min_j L_j - kmax (a chain
 //   of blends never falls more than the largest k below its smallest leaf: rm_decode.h [*]; Subtraction and Intersection
@@ -196,14 +197,23 @@ RM_DEV UnitBounds unit_bounds(const uint32_t* lunits, uint32_t n_units, const Wa
 RM_DEV unsigned long long wave_cull_lattice(const uint32_t* lunits, uint32_t n_units, float x, float y, float z, float thr, bool is_live,
                                             unsigned long long live_m) {
     const unsigned long long valid = n_units >= 64u ? ~0ull : ((1ull << n_units) - 1ull);
-    const WaveBall b = wave_ball(x, y, z, is_live, live_m);
-    const float T = __uint_as_float(wave_max_u32(is_live ? __float_as_uint(thr) : 0u)) * 1.000005f;  // thr >= 0 or NaN (wins)
-    // far: |p* - c| - R - rho > T, decided on the squares (every term is >= 0; a NaN or an infinity makes it false)
+    // ONE reduction: unit u is far for lane l when value_u(p_l) >= |p* - c| - R - |p_l - p*| > thr_l, i.e. for every live lane when
+    // |p* - c| - R > S = max over live lanes (|p_l - p*| + thr_l) -- sharper than rho + T (a maximum of sums, not a sum of maxima)
+    // and a wave reduction less.  thr >= 0 or NaN; a NaN's bit pattern is above +inf's and wins the maximum: nothing is far then.
+    const int first = __builtin_ctzll(live_m);  // (the caller has a live lane)
+    const float px = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), first));
+    const float py = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(y), first));
+    const float pz = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(z), first));
+    const float ex = x - px, ey = y - py, ez = z - pz;
+    const float e2 = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+    const float sl = (__builtin_amdgcn_sqrtf(e2) * 1.00001f + 1.0e-30f) + thr;  // v_sqrt_f32 is within an ulp
+    const float S = __uint_as_float(wave_max_u32(is_live ? __float_as_uint(sl) : 0u)) * 1.000005f;
+    // far: |p* - c| - R > S, decided on the squares (every term is >= 0; a NaN or an infinity makes it false)
     const uint32_t lane = threadIdx.x & 63u;
     const float* u = reinterpret_cast<const float*>(lunits) + (lane < n_units ? lane : 0u);
-    const float dx = u[0] - b.px, dy = u[n_units] - b.py, dz = u[2u * n_units] - b.pz;
+    const float dx = u[0] - px, dy = u[n_units] - py, dz = u[2u * n_units] - pz;
     const float d2 = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
-    const float s = (T + b.rho) + u[3u * n_units];
+    const float s = S + u[3u * n_units];
     return ~__builtin_amdgcn_ballot_w64(d2 > (s * s) * 1.000004f) & valid;
 }
 // margin_scale: scene_scale + |ro|_1 (the `prune_scale` of the kernels)
