@@ -33,6 +33,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0           # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP32_VECTOR_PEAK_TFLOPS = 157.3  # ditto
 BYTES_PER_PIXEL = 16             # one RGBA32F store per pixel: SURVEY 8(d) algorithmic bytes
+SALU_CYCLES_PER_INST = 4.33       # measured: tools/ubench_salu.hip
 VALU_CYCLES_PER_WAVE_INST = 2.0  # MI355X_MICROARCH.md: a wave64 VALU instruction occupies a SIMD-32 for 2 cycles
 
 
@@ -619,6 +620,12 @@ def valu_view(args, res, march_ms, evals, words, useful_occ=None):
             "measured_issue_cycles_per_inst": meas_floor,
             "frac_of_measured_valu_issue": meas_floor / cycles_per_inst if meas_floor else None,
             "lds_pipe_busy": pmc.get("SQ_ACTIVE_INST_LDS", 0.0) * 4.0 / (simds / 4.0) / (march_ms * 1e-3 * clock_ghz * 1e9) if pmc.get("SQ_ACTIVE_INST_LDS") else None,
+            # the other issue bound: a CU has ONE scalar unit for its four SIMDs -- a scalar instruction costs its SIMD 4.3 cycles
+            # (profiles/r03_ubench_scalar_issue_cycles.txt), and scalar and vector instructions of different waves issue side by side
+            "salu_insts_per_frame": pmc.get("SQ_INSTS_SALU"),
+            "scalar_issue_cycles_per_inst": SALU_CYCLES_PER_INST,
+            "scalar_unit_share_of_kernel_time": (pmc["SQ_INSTS_SALU"] * SALU_CYCLES_PER_INST / simds) / (march_ms * 1e-3 * clock_ghz * 1e9) if pmc.get("SQ_INSTS_SALU") else None,
+            "vector_issue_share_of_kernel_time": (meas_floor if meas_floor else floor_cycles) / cycles_per_inst,
             # lanes that carry a live ray (this run's wave counters), not lanes whose exec bit is set (the PMC figure, kept
             # beside it): a wave marching 64 rays in step executes the lanes whose rays ended early as dead work
             "useful_lane_occupancy": useful_occ,
