@@ -405,7 +405,8 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // (a specialised kernel with the generated material walk keeps those pairs in registers too)
     if (L.n_mrec != 0u && !(spec_fn && c->spec && c->spec->material_walk))
         L.spill_depth = std::max(L.spill_depth, 2u * c->decoded.mat_spill_depth + 3u * c->decoded.mat_xform_depth);
-    const size_t shmem = (size_t)(1024u + WPT * rmk::V5_WAVE_DWORDS) * 4u +
+    L.wave_dwords = rmk::V5_WAVE_DWORDS - ((spec_fn && c->spec && c->spec->taps4 && L.n_mrec == 0u) ? rmk::V5_TN_DWORDS : 0u);
+    const size_t shmem = (size_t)(1024u + WPT * L.wave_dwords) * 4u +
                          (size_t)L.spill_depth * 64u * WPT * 4u + cull_bytes +
                          (lds ? (size_t)(L.n_rec + L.n_grp + L.n_tree) * sizeof(RmRecord) : 0u) + kV5TailBytes +
                          (L.n_mrec != 0u ? 1024u : 0u);

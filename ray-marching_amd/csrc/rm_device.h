@@ -105,6 +105,8 @@ struct RmLaunch {
     uint32_t unit_mode;        // RM_UNITS_* (rm_units.h): 0 none, 1 lattice program (threshold rule), 2 blending chain
     float unit_kmax;           // the largest blend radius of a unit (the chain of blends never falls further below its smallest leaf)
     uint32_t spill_depth;      // LDS slots per lane this program needs: value stack, then 3 per transform level
+    uint32_t wave_dwords;      // LDS dwords of a march wave's private buffers (rm_kernel_v5.h V5_WAVE_DWORDS, or less: a generated kernel whose
+                               // taps run in one pass and that carries no materials has no use for the partial normals)
     uint32_t value_spill_depth; // the value-stack part of spill_depth (saved positions start at this slot)
     const float4* bounds;      // nullptr, or one world-space bounding sphere (centre, radius) per bounded primitive:
                                // programs with transforms (their miss tests use these instead of the parameters)

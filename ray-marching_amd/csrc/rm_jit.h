@@ -582,7 +582,7 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
 }
 
 inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune_kind, std::string* out,
-                            bool* walk_generated = nullptr) {
+                            bool* walk_generated = nullptr, bool* taps4_generated = nullptr) {
     const bool materials = !mrec.empty();
     const bool with_stats = (prune_kind & KERNEL_WITH_STATS) != 0;
     prune_kind &= PRUNE_KIND_MASK;
@@ -595,6 +595,7 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     bool taps4 = !(taps_knob && std::atoi(taps_knob) == 0);
     if (taps4 && rm_has_blend(rec) && jit_knob("RM_JIT_TAPS4_SMOOTH", 1) == 0) taps4 = false;
     taps4 = taps4 && generate_scene_code(rec, prune_kind, 4, &taps);
+    if (taps4_generated) *taps4_generated = taps4;
     std::string s;
     // hipRTC's built-in runtime header keeps the fixed-width integer types in a namespace of its own
     s += "typedef unsigned char rm_rtc_u8;\ntypedef unsigned short rm_rtc_u16;\ntypedef unsigned int rm_rtc_u32;\n"
@@ -784,6 +785,7 @@ struct Entry {
     std::string log;
     double compile_ms = 0.0;
     bool material_walk = false;  // the kernel carries the generated material walk (it needs no LDS stack for the material phase)
+    bool taps4 = false;          // ... the four-tap function (without materials it needs no partial normals in LDS: RmLaunch::wave_dwords)
     bool from_cache = false;     // the code object was read from the disk cache (compile_ms is then the time of that read)
     std::string cached_source;  // non-empty iff `code` came from the disk cache: if the loader rejects it, the file is
                                 // dropped and this source compiled afresh, once (rm_abi.hip specialised_kernel)
@@ -842,7 +844,7 @@ public:
         entries_[key] = e;
         Job job;
         job.entry = e;
-        if (!generate_source(rec, mrec, wpt, prune, &job.source, &e->material_walk)) {
+        if (!generate_source(rec, mrec, wpt, prune, &job.source, &e->material_walk, &e->taps4)) {
             e->state = Entry::FAILED;
             e->log = "program structure could not be turned into code";
             return e;

@@ -458,7 +458,12 @@ RM_DEV void spec_smooth_union4(LdsF r, const float (&a)[4], const float (&b)[4],
 constexpr uint32_t V5_RQ = 64u;   // ready buffer entries per wave (refilled only when empty)
 constexpr uint32_t V5_SQ = 64u;   // miss buffer entries per wave
 constexpr uint32_t V5_HQ = 128u;  // hit buffer entries per wave (64 are taken whenever 64 are waiting)
-constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 3u * 64u + 16u;  // (+ 16: the screen coordinates of the tile's 8 columns and 8 rows)
+// per wave: the three buffers, the screen coordinates of the tile's 8 columns and 8 rows, and LAST the partial normals of a tap phase
+// that takes its four taps one at a time or is followed by a material phase -- a generated kernel with the four-tap function and no
+// materials leaves those 768 bytes away (RmLaunch::wave_dwords): 25.6 -> 22.5 KB per workgroup for the metric scene, 7 instead of 6
+// workgroups per CU
+constexpr uint32_t V5_TN_DWORDS = 3u * 64u;
+constexpr uint32_t V5_WAVE_DWORDS = 4u * (V5_RQ + V5_SQ + V5_HQ) + 16u + V5_TN_DWORDS;
 
 // Miss-test tables of a program, built per workgroup in LDS from the decoded records (the
 // decoder stores each primitive's slot within its kind in RmRecord::p[6]):
@@ -729,16 +734,16 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     // ---- LDS carve-up (all offsets multiples of 16 bytes) ----
     float* res = reinterpret_cast<float*>(smem);                       // [1024] result code per ray (tile)
-    uint32_t* wbase = smem + POOL + wave * V5_WAVE_DWORDS;            // this wave's buffers
+    uint32_t* wbase = smem + POOL + wave * L.wave_dwords;             // this wave's buffers
     uint32_t* rq_rid = wbase;                                          // ready rays (SoA): id, direction
     float* rq_d = reinterpret_cast<float*>(wbase + V5_RQ);             // [3][V5_RQ]
     uint32_t* sq_rid = wbase + 4u * V5_RQ;                             // rays that ended without a hit: id, direction
     float* sq_v = reinterpret_cast<float*>(sq_rid + V5_SQ);            // [3][V5_SQ]
     uint32_t* hq_rid = sq_rid + 4u * V5_SQ;                            // hits waiting for their normal: id, position
     float* hq_v = reinterpret_cast<float*>(hq_rid + V5_HQ);            // [3][V5_HQ]
-    float* tn = hq_v + 3u * V5_HQ;                                     // [3][64] partial normals of the running tap phase
-    float* wxy = tn + 3u * 64u;                                        // [16] pt_screen.x of the tile's 8 columns, .y of its 8 rows (wgsl:41-43)
-    uint32_t* after = smem + POOL + WPT * V5_WAVE_DWORDS;
+    float* wxy = hq_v + 3u * V5_HQ;                                    // [16] pt_screen.x of the tile's 8 columns, .y of its 8 rows (wgsl:41-43)
+    float* tn = wxy + 16u;                                             // [3][64] partial normals of the running tap phase (absent when L.wave_dwords says so)
+    uint32_t* after = smem + POOL + WPT * L.wave_dwords;
     float* spill = reinterpret_cast<float*>(after) + wave * (L.spill_depth * 64u) + lane;  // [WPT][depth][64]
     float4* t_cone = reinterpret_cast<float4*>(after + WPT * L.spill_depth * 64u);         // [n_cone]
     float4* t_slab = t_cone + L.n_cone;                                                     // [2 * n_slab]
