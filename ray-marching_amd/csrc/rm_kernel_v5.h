@@ -136,19 +136,24 @@ RM_DEV uint32_t wave_max_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 // minimum over the lanes BELOW this one (+inf for lane 0); all 64 lanes active.  row_shr:1,2,3, row_shr:4, row_shr:8 scan a row
-// of 16, row_bcast:15 and row_bcast:31 carry the rows' totals on (a lane without a source keeps +inf; min is idempotent, so
-// it does not matter that a total may be counted twice); then one shift by a lane.
+// of 16, row_bcast:15 and row_bcast:31 carry the rows' totals on (a lane without a source keeps its value; min is idempotent, so
+// it does not matter that a total may be counted twice); then one shift by a lane across the whole wave (wave_shr:1).
+// Written as v_min_f32_dpp: through __builtin_fminf and update_dpp every step was four instructions (the identity moved in, the
+// DPP move, a canonicalising v_max, the v_min) and the last shift a ds_bpermute -- 65 vector instructions for the two scans of
+// a blending chain's mask where 16 do.  (v_min_f32 drops a NaN operand like fminf does; s_nop 1: a DPP source written by the
+// previous vector instruction needs two wait states, and the compiler does not look inside an asm.)
 RM_DEV float wave_exclusive_min(float x) {
-    const uint32_t inf = 0x7F800000u, v = __float_as_uint(x);
-    float s = fmin_(x, __uint_as_float(RM_DPP(inf, v, 0x111)));
-    s = fmin_(s, __uint_as_float(RM_DPP(inf, v, 0x112)));
-    s = fmin_(s, __uint_as_float(RM_DPP(inf, v, 0x113)));
-    s = fmin_(s, __uint_as_float(RM_DPP(inf, __float_as_uint(s), 0x114)));
-    s = fmin_(s, __uint_as_float(RM_DPP(inf, __float_as_uint(s), 0x118)));
-    s = fmin_(s, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(s), 0x142, 0xA, 0xF, false)));
-    s = fmin_(s, __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp((int)inf, (int)__float_as_uint(s), 0x143, 0xC, 0xF, false)));
-    const float up = __shfl_up(s, 1, 64);
-    return (threadIdx.x & 63u) == 0u ? __uint_as_float(inf) : up;
+    float s = x;
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %1, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
+    asm volatile("v_min_f32_dpp %0, %1, %0 row_shr:2 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
+    asm volatile("v_min_f32_dpp %0, %1, %0 row_shr:3 row_mask:0xf bank_mask:0xf" : "+v"(s) : "v"(x));
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf" : "+v"(s));
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf" : "+v"(s));
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(s));
+    asm volatile("s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(s));
+    float up = __uint_as_float(0x7F800000u);
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(up) : "v"(s));
+    return up;
 }
 struct WaveBall {  // wave-uniform: the live lanes' positions lie within rho of (px, py, pz)
     float px, py, pz, rho;
@@ -1085,115 +1090,115 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // The sequence of evaluations is the one the flat loop produced.
         uint32_t n_idle = tapping ? 0u : (uint32_t)__popcll(__ballot(mode == M_EMPTY));  // wave-uniform: lanes waiting for a ray
         for (;;) {
-        // (the interpreter kernels keep ONE copy of the evaluation for march steps and taps: their record loops are large, and the
-        // loop unswitched on `tapping` costs the lean kernel its registers)
-        bool tapping_i = tapping;
-        if constexpr (!SPEC) {
-            uint32_t t = tapping ? 1u : 0u;
-            asm volatile("" : "+v"(t));
-            tapping_i = __builtin_amdgcn_readfirstlane(t) != 0u;
-        }
-        float ex, ey, ez, thr = inf_f;
-        bool is_live;
-        uint32_t sgx = 0u, sgy = 0u, sgz = 0u;
-        const uint32_t he = hq_n + lane;  // this lane's hit-buffer entry in a tap phase (< V5_HQ for every lane)
-        if (tapping_i) {  // pos + k_t * eps (wgsl:138-141); k_t * eps = +-eps exactly
-            tap_signs(tap_t, sgx, sgy, sgz);
-            ex = hq_v[he] + __uint_as_float(__float_as_uint(eps) ^ sgx);
-            ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
-            ez = hq_v[2u * V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgz);
-            is_live = lane < tap_n;
+            // (the interpreter kernels keep ONE copy of the evaluation for march steps and taps: their record loops are large, and the
+            // loop unswitched on `tapping` costs the lean kernel its registers)
+            bool tapping_i = tapping;
+            if constexpr (!SPEC) {
+                uint32_t t = tapping ? 1u : 0u;
+                asm volatile("" : "+v"(t));
+                tapping_i = __builtin_amdgcn_readfirstlane(t) != 0u;
+            }
+            float ex, ey, ez, thr = inf_f;
+            bool is_live;
+            uint32_t sgx = 0u, sgy = 0u, sgz = 0u;
+            const uint32_t he = hq_n + lane;  // this lane's hit-buffer entry in a tap phase (< V5_HQ for every lane)
+            if (tapping_i) {  // pos + k_t * eps (wgsl:138-141); k_t * eps = +-eps exactly
+                tap_signs(tap_t, sgx, sgy, sgz);
+                ex = hq_v[he] + __uint_as_float(__float_as_uint(eps) ^ sgx);
+                ey = hq_v[V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgy);
+                ez = hq_v[2u * V5_HQ + he] + __uint_as_float(__float_as_uint(eps) ^ sgz);
+                is_live = lane < tap_n;
 #ifdef RM_PRUNE_PLUMBING
-            // the tap is eps * sqrt(3) away from the hit position, where the scene value was sd_hit ("Pruning")
-            thr = __uint_as_float(hq_rid[he] & ~1023u) * 1.00001f + 1.75e-4f +
-                  kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+                // the tap is eps * sqrt(3) away from the hit position, where the scene value was sd_hit ("Pruning")
+                thr = __uint_as_float(hq_rid[he] & ~1023u) * 1.00001f + 1.75e-4f +
+                      kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
 #endif
-        } else {
-            ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
-            is_live = mode == M_MARCH;
-            thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
-        }
-        const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
+            } else {
+                ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
+                is_live = mode == M_MARCH;
+                thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
+            }
+            const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
 #ifndef RM_NO_WAVE_STATS
-        n_iter++;
-        n_live += (uint32_t)__popcll(live_m);
+            n_iter++;
+            n_live += (uint32_t)__popcll(live_m);
 #endif
 #ifdef RM_PRIO_LONG_RAYS
-        // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
-        // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
-        // issue priority: the chain runs at the lone-wave rate and the short rays fill in behind it.
-        if (!tapping_i) {
-            const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && itr >= (RM_PRIO_LONG_RAYS << 10)));
-            if (old_rays != 0u) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
-        const float sd = eval_scene(ex, ey, ez, thr, is_live, live_m);
-
-        if (tapping_i) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
-            const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
-            const float vy = __uint_as_float(__float_as_uint(sd) ^ sgy);
-            const float vz = __uint_as_float(__float_as_uint(sd) ^ sgz);
-            // the partial sum waits in LDS between taps, not in three registers that every march iteration would carry
-            const float nx = tap_t == 0u ? vx : tn[lane] + vx;
-            const float ny = tap_t == 0u ? vy : tn[64u + lane] + vy;
-            const float nz = tap_t == 0u ? vz : tn[128u + lane] + vz;
-            if (++tap_t == 4u && !tagged) {
-                if (is_live) res[hq_rid[he] & 1023u] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
-                tap_t = TAP_IDLE;
-                break;
+            // A ray that needs hundreds of steps is a serial chain of that many evaluations; at full load a wave gets a
+            // fifth of its SIMD's issue slots, so such a ray started late IS the kernel's tail.  Waves that carry one get
+            // issue priority: the chain runs at the lone-wave rate and the short rays fill in behind it.
+            if (!tapping_i) {
+                const uint32_t old_rays = (uint32_t)__popcll(__ballot(is_live && itr >= (RM_PRIO_LONG_RAYS << 10)));
+                if (old_rays != 0u) __builtin_amdgcn_s_setprio(3);
+                else __builtin_amdgcn_s_setprio(0);
             }
-            tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
-            if (tap_t == 4u) break;  // (tagged program: the material phase follows)
-            continue;                // the next tap of the same hits
-        }
+#endif
+            const float sd = eval_scene(ex, ey, ez, thr, is_live, live_m);
 
-        // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
-        // Written on wave masks (64-bit scalars) with explicit selects: left to itself the compiler turned the lane
-        // predicates into 0/1 integers and back (17 vector instructions for what takes 7).
-        const unsigned long long hit_mask = live_m & __ballot(sd < L.min_dist);                       // wgsl:97
-        const unsigned long long on_m = live_m & ~hit_mask;                                           // (a NaN is not a hit)
-        const unsigned long long esc_m = on_m & __ballot(sd > L.max_dist);                            // wgsl:109-111
-        const unsigned long long go_m = on_m & ~esc_m;
-        sc = select_by_mask(sc, sc + sd, go_m);                                                       // wgsl:114
-        itr = select_by_mask(itr, itr + 1024u, go_m);
+            if (tapping_i) {  // n (+)= k_t * f; products with +-1 are exact (wgsl:138-143)
+                const float vx = __uint_as_float(__float_as_uint(sd) ^ sgx);
+                const float vy = __uint_as_float(__float_as_uint(sd) ^ sgy);
+                const float vz = __uint_as_float(__float_as_uint(sd) ^ sgz);
+                // the partial sum waits in LDS between taps, not in three registers that every march iteration would carry
+                const float nx = tap_t == 0u ? vx : tn[lane] + vx;
+                const float ny = tap_t == 0u ? vy : tn[64u + lane] + vy;
+                const float nz = tap_t == 0u ? vz : tn[128u + lane] + vz;
+                if (++tap_t == 4u && !tagged) {
+                    if (is_live) res[hq_rid[he] & 1023u] = shade_hit(nx, ny, nz, hq_v[he], hq_v[V5_HQ + he], hq_v[2u * V5_HQ + he]);  // wgsl:98-103
+                    tap_t = TAP_IDLE;
+                    break;
+                }
+                tn[lane] = nx; tn[64u + lane] = ny; tn[128u + lane] = nz;
+                if (tap_t == 4u) break;  // (tagged program: the material phase follows)
+                continue;                // the next tap of the same hits
+            }
+
+            // ---- C. march bookkeeping (wgsl:97-114); finished rays leave their lane ----
+            // Written on wave masks (64-bit scalars) with explicit selects: left to itself the compiler turned the lane
+            // predicates into 0/1 integers and back (17 vector instructions for what takes 7).
+            const unsigned long long hit_mask = live_m & __ballot(sd < L.min_dist);                       // wgsl:97
+            const unsigned long long on_m = live_m & ~hit_mask;                                           // (a NaN is not a hit)
+            const unsigned long long esc_m = on_m & __ballot(sd > L.max_dist);                            // wgsl:109-111
+            const unsigned long long go_m = on_m & ~esc_m;
+            sc = select_by_mask(sc, sc + sd, go_m);                                                       // wgsl:114
+            itr = select_by_mask(itr, itr + 1024u, go_m);
 #ifdef RM_PRUNE_PLUMBING  // only pruning kernels read it
-        thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
+            thr_base = select_by_mask(thr_base, __builtin_fabsf(sd) * 2.00002f, go_m);  // the next point is |sd| |rd| away
 #endif
-        const unsigned long long miss_mask = esc_m | (go_m & __ballot(itr >= iter_limit));             // loop bound, wgsl:90
-        const unsigned long long done_m = hit_mask | miss_mask;
-        if (done_m == 0ull) continue;  // every live ray goes on: nothing section A asks about has changed
-        const bool hit = is_live && sd < L.min_dist, miss = lane_of(miss_mask, lane);
-        if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
-            if (hit) {
-                const uint32_t e = hq_n + lane_rank(hit_mask);
+            const unsigned long long miss_mask = esc_m | (go_m & __ballot(itr >= iter_limit));             // loop bound, wgsl:90
+            const unsigned long long done_m = hit_mask | miss_mask;
+            if (done_m == 0ull) continue;  // every live ray goes on: nothing section A asks about has changed
+            const bool hit = is_live && sd < L.min_dist, miss = lane_of(miss_mask, lane);
+            if (hit_mask != 0ull) {  // -> hit buffer (capacity 128: a tap phase takes 64 as soon as 64 are waiting)
+                if (hit) {
+                    const uint32_t e = hq_n + lane_rank(hit_mask);
 #ifdef RM_PRUNE_PLUMBING
-                // |sd| of the hit, rounded up to 22 bits, rides in the upper bits of the entry's ray id (< 1024): the
-                // pruning threshold of its normal taps ("Pruning"); a NaN stays a NaN (nothing is skipped then)
-                hq_rid[e] = (itr & 1023u) | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);
+                    // |sd| of the hit, rounded up to 22 bits, rides in the upper bits of the entry's ray id (< 1024): the
+                    // pruning threshold of its normal taps ("Pruning"); a NaN stays a NaN (nothing is skipped then)
+                    hq_rid[e] = (itr & 1023u) | ((__float_as_uint(__builtin_fabsf(sd)) + 1023u) & ~1023u);
 #else
-                hq_rid[e] = itr & 1023u;
+                    hq_rid[e] = itr & 1023u;
 #endif
-                hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
-                mode = M_EMPTY;
+                    hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
+                    mode = M_EMPTY;
+                }
+                hq_n += (uint32_t)__popcll(hit_mask);
             }
-            hq_n += (uint32_t)__popcll(hit_mask);
-        }
-        if (miss_mask != 0ull) {
-            const uint32_t n_miss = (uint32_t)__popcll(miss_mask);
-            if (sq_n + n_miss > V5_SQ) flush_misses();
-            if (miss) {
-                const uint32_t e = sq_n + lane_rank(miss_mask);
-                sq_rid[e] = itr & 1023u;
-                sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
-                mode = M_EMPTY;
+            if (miss_mask != 0ull) {
+                const uint32_t n_miss = (uint32_t)__popcll(miss_mask);
+                if (sq_n + n_miss > V5_SQ) flush_misses();
+                if (miss) {
+                    const uint32_t e = sq_n + lane_rank(miss_mask);
+                    sq_rid[e] = itr & 1023u;
+                    sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
+                    mode = M_EMPTY;
+                }
+                sq_n += n_miss;
             }
-            sq_n += n_miss;
-        }
-        // back to section A when it has something to do: no ray left marching, enough idle lanes for a refill (refill_min; when
-        // the pool is exhausted A retires them), or 64 hits waiting for their normals
-        n_idle += (uint32_t)__popcll(done_m);
-        if ((live_m & ~done_m) == 0ull || n_idle >= refill_min || hq_n >= 64u) break;
+            // back to section A when it has something to do: no ray left marching, enough idle lanes for a refill (refill_min; when
+            // the pool is exhausted A retires them), or 64 hits waiting for their normals
+            n_idle += (uint32_t)__popcll(done_m);
+            if ((live_m & ~done_m) == 0ull || n_idle >= refill_min || hq_n >= 64u) break;
         }
     }
     if (sq_n != 0u) flush_misses();
