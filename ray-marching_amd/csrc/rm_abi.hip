@@ -440,6 +440,12 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     // persistent grid: about as many workgroups as fit the chip (LDS, 32 waves per CU), never more than tiles
     uint32_t per_cu = (uint32_t)std::min<size_t>(32u / WPT, (160u * 1024u) / shmem);
     if (per_cu < 1u) per_cu = 1u;
+    // ... but never more than 24 waves of ONE launch on a CU: where a seventh workgroup would fit (kernels of at most 72 vector
+    // registers and 22.8 KB of LDS), a frame drawn alone is slower with it (a tile's four waves get a seventh of the CU instead of a
+    // sixth, and the launch ends with its last tiles: -4 %), while the free slot lets the next frame's launch start on the same CU
+    // (frames in flight +6 %).  RM_WG_PER_CU_CAP (A/B): another cap, 0 none.
+    static const int per_cu_cap = std::getenv("RM_WG_PER_CU_CAP") ? std::atoi(std::getenv("RM_WG_PER_CU_CAP")) : 24 / WPT;
+    if (per_cu_cap > 0 && per_cu > (uint32_t)per_cu_cap) per_cu = (uint32_t)per_cu_cap;
     const uint32_t n_wg = std::min<uint32_t>(n_tiles, (uint32_t)std::max(1, c->cu_count) * per_cu);
     dim3 grid(n_wg, 1, n_frames);
     if (int rc = ensure_stats(c, L, (size_t)n_wg * n_frames * WPT)) return rc;

@@ -288,19 +288,36 @@ RM_DEV float map_scene_chain(const Prog& prog, uint32_t n_rec, float x, float y,
         acc = cls >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
     };
     if (masked) {
+        // Scalar instructions are the dear ones here (4.3 cycles each per SIMD, rm_kernel_v5.h "The scalar unit"): record 0 -- the one
+        // record that pushes -- is handled in front of the loop, so the loop body asks no "is this record 0"; the bit of a record is
+        // cleared with one s_bitset0_b64 instead of the three instructions of m & (m - 1).
         unsigned long long m = need;  // (bits at and above n_rec are clear)
+        if (m & 1ull) {
+            prog.load(0u, opa, pa);
+            opa = __builtin_amdgcn_readfirstlane(opa);
+            acc = RM_OP_KIND(opa) == RM_KIND_SPHERE ? sdf_sphere_t<FAST>(x, y, z, pa, tiny) : sdf_box_t<FAST>(x, y, z, pa, tiny);
+        }
+        m &= ~1ull;
         if (m == 0ull) return acc;
-        uint32_t ca = (uint32_t)__builtin_ctzll(m), cb = 0u;
-        m &= m - 1ull;
-        prog.load(ca, opa, pa);
-        for (;;) {  // record ca waits in (opa, pa)
+        auto fused = [&](uint32_t op, const float (&p)[7]) {
+            op = __builtin_amdgcn_readfirstlane(op);
+            const float b = (op & (1u << 16)) ? sdf_sphere_t<FAST>(x, y, z, p, tiny) : sdf_box_t<FAST>(x, y, z, p, tiny);  // RM_OP_FASTCLASS 1, 3: sphere
+            acc = RM_OP_FASTCLASS(op) >= 3u ? vmax_negb(acc, b) : vmin(acc, b);  // wgsl:248-252 / :242-246
+        };
+        auto take = [&]() -> uint32_t {  // the lowest record still to do (the caller knows there is one)
+            const uint32_t c = (uint32_t)__builtin_ctzll(m);
+            asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(c));
+            return c;
+        };
+        prog.load(take(), opa, pa);
+        for (;;) {  // a record waits in (opa, pa)
             const bool more = m != 0ull;
-            if (more) { cb = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; prog.load(cb, opb, pb); }
-            apply(ca, opa, pa);
+            if (more) prog.load(take(), opb, pb);
+            fused(opa, pa);
             if (!more) break;
             const bool more2 = m != 0ull;
-            if (more2) { ca = (uint32_t)__builtin_ctzll(m); m &= m - 1ull; prog.load(ca, opa, pa); }
-            apply(cb, opb, pb);
+            if (more2) prog.load(take(), opa, pa);
+            fused(opb, pb);
             if (!more2) break;
         }
         return acc;

@@ -625,6 +625,17 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
     // sits above 80 loses by the same cap (balanced tree +7 %, materials +3 %, transforms +1 %: profiles/r03_refill_threshold_and_forced_occupancy.txt).
     // RM_JIT_WAVES_PER_EU (A/B): n forces n waves per SIMD for every kernel, 0 none.
     int waves = prune_kind == PRUNE_BLEND ? 6 : 0;
+    // A CHAIN ("a op b op c ...": every record after the first a leaf fused with its operator) without blends or materials and
+    // with the four-tap function takes 73 vector registers -- one more than 7 waves per SIMD allow -- and 22.5 KB of LDS per
+    // workgroup (no partial normals, RmLaunch::wave_dwords): room for 7 workgroups on a CU.  Capped at 72 it spills one register;
+    // a launch still takes only 6 workgroups per CU (rm_abi.hip launch_v5_w), so a frame drawn alone runs as before (-0.5 .. +0.8 %)
+    // and the seventh slot goes to the NEXT frame's launch: two to eight frames in flight +4 .. +7 % (profiles/r03_seven_waves_per_simd_ab.txt).
+    bool chain = !materials && taps4 && prune_kind != PRUNE_BLEND && !rec.empty();
+    for (size_t i = 1; chain && i < rec.size(); i++) {
+        const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
+        chain = (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX || kind == RM_KIND_CYLINDER || kind == RM_KIND_PLANE) && mode != RM_MODE_PUSH;
+    }
+    if (chain) waves = 7;
     if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) waves = std::atoi(w);
     if (waves > 0) {
         std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", waves, waves);
