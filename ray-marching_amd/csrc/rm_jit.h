@@ -581,8 +581,12 @@ inline bool structure_allows_bound_walk(const std::vector<RmRecord>& rec) {
     return smooth && depth <= 1;
 }
 
+// capped_out (nullable): a second source of the same kernel capped at 80 vector registers (6 waves per SIMD), or left empty -- for the
+// kernels that may sit a few registers above 80 and are faster with one or two of them spilled: the trees of a lattice program (the
+// balanced tree of the metric scene's leaves: 84 registers, 0.40 -> 0.38 ms capped).  Whether the cap is cheap shows only in the compiled
+// code: compile_best compiles the capped source first and keeps it iff it spills at most eight registers.
 inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<RmRecord>& mrec, int wpt, int prune_kind, std::string* out,
-                            bool* walk_generated = nullptr, bool* taps4_generated = nullptr) {
+                            bool* walk_generated = nullptr, bool* taps4_generated = nullptr, std::string* capped_out = nullptr) {
     const bool materials = !mrec.empty();
     const bool with_stats = (prune_kind & KERNEL_WITH_STATS) != 0;
     prune_kind &= PRUNE_KIND_MASK;
@@ -636,16 +640,24 @@ inline bool generate_source(const std::vector<RmRecord>& rec, const std::vector<
         chain = (kind == RM_KIND_SPHERE || kind == RM_KIND_BOX || kind == RM_KIND_CYLINDER || kind == RM_KIND_PLANE) && mode != RM_MODE_PUSH;
     }
     if (chain) waves = 7;
-    if (const char* w = std::getenv("RM_JIT_WAVES_PER_EU")) waves = std::atoi(w);
-    if (waves > 0) {
-        std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", waves, waves);
-        s += line;
-    }
-    std::snprintf(line, sizeof line,
-                  "extern \"C\" __global__ __launch_bounds__(%d) void %s(RmLaunch L, rmk::V5Work work, uint32_t n_tiles, "
-                  "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true, %s>(L, work, n_tiles, refill_min);\n}\n",
-                  64 * wpt, kernel_name(), wpt, materials ? "true" : "false");
-    s += line;
+    const bool knob = std::getenv("RM_JIT_WAVES_PER_EU") != nullptr;
+    if (knob) waves = std::atoi(std::getenv("RM_JIT_WAVES_PER_EU"));
+    const bool probe = capped_out && !knob && waves == 0 && prune_kind == PRUNE_LATTICE && !materials && jit_knob("RM_JIT_PROBE_CAP", 1) != 0;
+    auto kernel_text = [&](int w) {
+        std::string k;
+        if (w > 0) {
+            std::snprintf(line, sizeof line, "__attribute__((amdgpu_waves_per_eu(%d, %d)))\n", w, w);
+            k += line;
+        }
+        std::snprintf(line, sizeof line,
+                      "extern \"C\" __global__ __launch_bounds__(%d) void %s(RmLaunch L, rmk::V5Work work, uint32_t n_tiles, "
+                      "uint32_t refill_min) {\n    rmk::rm_render_v5_body<rmk::ProgLds, true, %d, false, true, %s>(L, work, n_tiles, refill_min);\n}\n",
+                      64 * wpt, kernel_name(), wpt, materials ? "true" : "false");
+        k += line;
+        return k;
+    };
+    if (capped_out) *capped_out = probe ? s + kernel_text(6) : std::string();
+    s += kernel_text(waves);
     *out = std::move(s);
     return true;
 }
@@ -786,6 +798,64 @@ inline bool compile(const std::string& src, std::vector<char>* code, std::string
     return ok;
 }
 
+// Scratch bytes per lane of `kernel` in a code object (the `private_segment_fixed_size` of its kernel descriptor, symbol
+// "<kernel>.kd": 4 bytes per spilled vector register), or UINT32_MAX when the file does not parse.  ELF64, little endian.
+inline uint32_t code_object_scratch_bytes(const std::vector<char>& co, const char* kernel) {
+    auto rd = [&](uint64_t off, void* dst, size_t n) { if (off > co.size() || n > co.size() - off) return false; std::memcpy(dst, co.data() + off, n); return true; };
+    uint64_t shoff = 0;
+    uint16_t shentsize = 0, shnum = 0;
+    if (co.size() < 64 || std::memcmp(co.data(), "\177ELF\2\1", 6) != 0 || !rd(0x28, &shoff, 8) || !rd(0x3A, &shentsize, 2) || !rd(0x3C, &shnum, 2) ||
+        shentsize < 64) return UINT32_MAX;
+    struct Sec { uint32_t type, link; uint64_t addr, offset, size; };
+    auto section = [&](uint32_t i, Sec* o) {
+        const uint64_t b = shoff + (uint64_t)i * shentsize;
+        return i < shnum && rd(b + 4, &o->type, 4) && rd(b + 0x10, &o->addr, 8) && rd(b + 0x18, &o->offset, 8) && rd(b + 0x20, &o->size, 8) && rd(b + 0x28, &o->link, 4);
+    };
+    const std::string want = std::string(kernel) + ".kd";
+    for (uint32_t i = 0; i < shnum; i++) {
+        Sec sym, str;
+        if (!section(i, &sym) || sym.type != 2u /* SHT_SYMTAB */ || !section(sym.link, &str)) continue;
+        for (uint64_t k = 0; k + 24 <= sym.size; k += 24) {
+            uint32_t name = 0;
+            uint16_t shndx = 0;
+            uint64_t value = 0;
+            if (!rd(sym.offset + k, &name, 4) || !rd(sym.offset + k + 6, &shndx, 2) || !rd(sym.offset + k + 8, &value, 8)) return UINT32_MAX;
+            if (name >= str.size || str.size - name < want.size() + 1) continue;
+            std::string got(want.size() + 1, 0);
+            if (!rd(str.offset + name, &got[0], got.size()) || got.compare(0, want.size(), want) != 0 || got[want.size()] != 0) continue;
+            Sec home;
+            uint32_t scratch = 0;
+            if (!section(shndx, &home) || value < home.addr || !rd(value - home.addr + home.offset + 4, &scratch, 4)) return UINT32_MAX;
+            return scratch;
+        }
+    }
+    return UINT32_MAX;
+}
+
+// `src`, or -- when generate_source offered one -- the capped form of the same kernel if it spills at most eight registers (measured: the
+// balanced tree with four spilled 0.403 -> 0.381 ms, the blending chain with nine 3.44 -> 3.27; a kernel that needs many more than 80 loses).
+constexpr uint32_t kCapScratchBytes = 32u;
+// *used (nullable): the source whose code object `code` holds.
+inline bool compile_best(const std::string& src, const std::string& capped, std::vector<char>* code, std::string* log, double* ms,
+                         bool* from_cache = nullptr, std::string* used = nullptr) {
+    double ms_cap = 0.0;
+    if (!capped.empty()) {
+        bool cached = false;
+        if (compile(capped, code, log, &ms_cap, &cached) && code_object_scratch_bytes(*code, kernel_name()) <= kCapScratchBytes) {
+            *log += "\nkernel capped at 80 vector registers (6 waves per SIMD): " + std::to_string(code_object_scratch_bytes(*code, kernel_name())) + " bytes of scratch per lane";
+            if (ms) *ms = ms_cap;
+            if (from_cache) *from_cache = cached;
+            if (used) *used = capped;
+            return true;
+        }
+        code->clear();
+    }
+    const bool ok = compile(src, code, log, ms, from_cache);
+    if (ms) *ms += ms_cap;
+    if (used) *used = src;
+    return ok;
+}
+
 // ---- cache ------------------------------------------------------------------------------------------
 struct Entry {
     enum State : int { COMPILING = 0, READY = 1, FAILED = 2 };
@@ -837,7 +907,7 @@ public:
         // A/B knobs of the generator as the environment holds them now (so that a process may compare two settings)
         static const char* const knobs[] = {"RM_JIT_GUARD_FENCE", "RM_JIT_MATERIAL_WALK",
                                             "RM_JIT_PRIO_LONG_RAYS", "RM_JIT_PRUNE_STATS", "RM_JIT_SCHED_BARRIER", "RM_JIT_SCHED_BARRIER_TAPS",
-                                            "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU", "RM_JIT_UNIT_TEST", "RM_JIT_UNIT_GROUPS"};
+                                            "RM_JIT_SUB_TESTS", "RM_JIT_TAPS4", "RM_JIT_TAPS4_SMOOTH", "RM_JIT_WAVES_PER_EU", "RM_JIT_UNIT_TEST", "RM_JIT_UNIT_GROUPS", "RM_JIT_PROBE_CAP"};
         std::string knob_key;
         for (const char* name : knobs)
             if (const char* v = std::getenv(name)) knob_key += std::string("|") + name + "=" + v;
@@ -855,7 +925,7 @@ public:
         entries_[key] = e;
         Job job;
         job.entry = e;
-        if (!generate_source(rec, mrec, wpt, prune, &job.source, &e->material_walk, &e->taps4)) {
+        if (!generate_source(rec, mrec, wpt, prune, &job.source, &e->material_walk, &e->taps4, &job.capped)) {
             e->state = Entry::FAILED;
             e->log = "program structure could not be turned into code";
             return e;
@@ -885,7 +955,7 @@ public:
     }
 
 private:
-    struct Job { std::shared_ptr<Entry> entry; std::string source; };
+    struct Job { std::shared_ptr<Entry> entry; std::string source, capped; };
     void run() {
         for (;;) {
             Job job;
@@ -900,11 +970,12 @@ private:
             std::string log;
             double ms = 0.0;
             bool from_cache = false;
-            const bool ok = compile(job.source, &code, &log, &ms, &from_cache);
+            std::string used;
+            const bool ok = compile_best(job.source, job.capped, &code, &log, &ms, &from_cache, &used);
             {
                 std::lock_guard<std::mutex> g(job.entry->m);
                 job.entry->from_cache = ok && from_cache;
-                if (ok && from_cache) job.entry->cached_source = std::move(job.source);
+                if (ok && from_cache) job.entry->cached_source = std::move(used);
                 job.entry->code = std::move(code);
                 job.entry->log = std::move(log);
                 job.entry->compile_ms = ms;

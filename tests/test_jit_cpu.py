@@ -215,6 +215,28 @@ def test_generated_kernel_compiles_for_gfx950(oracle, name, prune):
     assert nbytes > 4096 and ms > 0
 
 
+def test_tree_kernels_are_capped_at_80_registers_when_that_is_cheap(oracle, monkeypatch):
+    """The kernel of a lattice TREE may need a few registers more than 6 waves per SIMD allow (the balanced tree of the metric scene's
+    leaves: 84).  The compiler is asked for the capped form first and it is kept iff the code object's kernel descriptor shows at most
+    32 bytes of scratch per lane (rm_jit.h compile_best, code_object_scratch_bytes); a chain is compiled for 7 waves, without a probe."""
+    monkeypatch.setenv("RM_JIT_CACHE_DIR", "off")
+    cc, w = serialize(oracle, scenes.g32_balanced())
+    rc, ms, nbytes, log = renderer.jit_compile(cc, w, prune=True)
+    if rc != _ffi.RM_OK and "could not be loaded" in log:
+        pytest.skip("libhiprtc is not installed: " + log)
+    assert rc == _ffi.RM_OK, log
+    m = re.search(r"kernel capped at 80 vector registers \(6 waves per SIMD\): (\d+) bytes of scratch per lane", log)
+    assert m and int(m.group(1)) <= 32, log
+    monkeypatch.setenv("RM_JIT_PROBE_CAP", "0")
+    rc, ms, nbytes, log = renderer.jit_compile(cc, w, prune=True)
+    assert rc == _ffi.RM_OK and "capped" not in log
+    monkeypatch.delenv("RM_JIT_PROBE_CAP")
+    cc, w = serialize(oracle, scenes.g32())
+    rc, ms, nbytes, log = renderer.jit_compile(cc, w, prune=True)
+    assert rc == _ffi.RM_OK and "capped" not in log
+    assert "amdgpu_waves_per_eu(7, 7)" in renderer.jit_source(cc, w, prune=True)
+
+
 def test_disk_cache_of_compiled_kernels(oracle, tmp_path):
     """RM_JIT_CACHE_DIR: the second compilation of the same kernel by a NEW process is a file read; another structure
     or a corrupted file is compiled afresh.  (A subprocess per step: the library reads the variable at compile time

@@ -2,6 +2,8 @@
 (0.4, 0.7, 0.1) (wgsl:105) and lists a material system as future work (README.md:11).  The semantics are this repo's
 (oracle/rm_oracle.c map_scene_impl), so parity with the reference is undefined; the oracle is pinned by hand-derived
 values and by C == numpy, the host mirrors by word-for-word serialisation.  CPU only."""
+import re
+
 import numpy as np
 import pytest
 
@@ -125,7 +127,8 @@ def test_generated_kernel_of_a_tagged_program():
     # the distance code (march function and four-tap function) is the untagged scene's, text for text ...
     def body(s):
         end = s.index("RM_DEV uint32_t map_scene_material_spec") if "map_scene_material_spec(const" in s else s.index('extern "C"')
-        return s[s.index("map_scene_spec"):end].replace("namespace rmk {\n", "").replace("template <bool FAST>\n", "").rstrip()
+        text = s[s.index("map_scene_spec"):end].replace("namespace rmk {\n", "").replace("template <bool FAST>\n", "").rstrip()
+        return re.sub(r"\n__attribute__\(\(amdgpu_waves_per_eu\(\d, \d\)\)\)$", "", text)      # (a chain without materials is compiled for 7 waves per SIMD)
     tagged_src = renderer.jit_source(cct, wt)
     assert body(tagged_src) == body(renderer.jit_source(cc8, w8))
     # ... and the material walk follows it as straight-line code: (distance, index) pairs, the tag read as data
