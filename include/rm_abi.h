@@ -221,8 +221,8 @@ int rm_validate_program(uint32_t cmd_count, const uint32_t* words, uint32_t n_wo
 
 /* Diagnostics (pure host code): what the upload-time decoder makes of a command stream.  out[0..n_out) receives, in this order
  * (indices RM_PROGRAM_*): records, cone entries and slab entries of the miss-test tables, leaves left out of those tables
- * because they sit in the right operand of a Subtraction, paired far-test groups, value-stack slots the accumulator machine
- * spills, then four 0/1 facts -- chain program (stack-free interpreter loop), prunable (far-primitive pruning applies),
+ * because they sit in the right operand of a Subtraction, units of wave-level culling (RM_PROGRAM_GROUPS: the name is round 2's, when
+ * they were pairs of leaves; 0 when the program has none), value-stack slots the accumulator machine spills, then four 0/1 facts -- chain program (stack-free interpreter loop), prunable (far-primitive pruning applies),
  * miss test on lower bounds applies, program has space transformations --, the sphere + box leaves the program evaluates
  * (subtracted ones included), and what the automatic pruning decision (RM_OPT_PRUNE = 2) gives this program: 0 the plain kernel,
  * 1 / 2 as RM_INFO_PRUNED.

@@ -367,7 +367,7 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     if (L.n_rec == 0u && L.max_dist < L.min_dist) cull = false;  // see launch_multi_w
     L.n_cull = cull ? L.n_rec : 0u;
     // interpreter kernels: which map_scene loop a chain program takes (RmLaunch::flags).  RM_CHAIN_MODE (diagnostics):
-    // 0 the general record loop, 1 the chain loop, 2 the chain loop with far pairs skipped (default)
+    // 0 the general record loop, 1 the chain / tree loops over every record, 2 (default) over the records the wave's unit mask names / leaves
     static const int chain_mode = std::getenv("RM_CHAIN_MODE") ? std::atoi(std::getenv("RM_CHAIN_MODE")) : 2;
     const bool chain = c->decoded.is_chain && chain_mode > 0;
     // ... and whether the interpreter uses the wave-level culling mask (bit 3): 2 (default) yes, wherever the program has units
