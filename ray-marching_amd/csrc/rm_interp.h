@@ -209,7 +209,8 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
 #pragma unroll
         for (int k = 0; k < R; k++) acc[k] = fmax_(a[k], b[k]);
     } else {  // RM_MODE_SMOOTH, extension: min(a,b) - h*h*k/4, h = max(k - |a-b|, 0)/k; k <= 0: plain min
-        const float kk = p[0];
+        // (k as a scalar: every lane fetched the same record, and a branch on a vector register is divergent control flow)
+        const float kk = __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(p[0])));
 #pragma unroll
         for (int k = 0; k < R; k++) {
             float v = fmin_(a[k], b[k]);

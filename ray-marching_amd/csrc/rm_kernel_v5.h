@@ -231,12 +231,15 @@ RM_DEV unsigned long long wave_cull_blend(const uint32_t* lunits, uint32_t n_uni
     const UnitBounds u = unit_bounds(lunits, n_units, b);
     const bool in_range = lane < n_units;
     const float inf = __uint_as_float(0x7F800000u);
-    const bool blends = in_range && (u.kind == RM_UNIT_UM || u.kind == RM_UNIT_START);
+    // (the lane predicates are combined with & and |, not && and ||: short-circuit evaluation of a lane predicate is divergent control
+    // flow -- an exec mask saved, narrowed and restored per operator, a dozen scalar instructions where one s_and_b64 does)
+    const bool blends = in_range & ((u.kind == RM_UNIT_UM) | (u.kind == RM_UNIT_START));
     const float a_hi = wave_exclusive_min(blends ? u.H : inf);
     const float a_lo = wave_exclusive_min(blends ? u.L : inf) - kmax;
     const bool is_um = u.kind == RM_UNIT_UM, is_sub = u.kind == RM_UNIT_SUB, is_int = u.kind == RM_UNIT_INTER;
-    const bool skip = (is_um && u.L >= (a_hi + u.k) + m) || (is_sub && u.L + a_lo >= m) || (is_int && u.H <= a_lo - m);
-    const bool restart = is_um && u.H <= (a_lo - u.k) - m;
+    const bool far_um = u.L >= (a_hi + u.k) + m, far_sub = u.L + a_lo >= m, far_int = u.H <= a_lo - m;  // (false on a NaN)
+    const bool skip = (is_um & far_um) | (is_sub & far_sub) | (is_int & far_int);
+    const bool restart = is_um & (u.H <= (a_lo - u.k) - m);
     const unsigned long long opaque_m = __builtin_amdgcn_ballot_w64(u.kind == RM_UNIT_OPAQUE) & valid;
     const unsigned long long before_opaque = opaque_m ? ((1ull << __builtin_ctzll(opaque_m)) - 1ull) : ~0ull;
     const unsigned long long restart_m = __builtin_amdgcn_ballot_w64(restart) & valid & before_opaque;
@@ -244,7 +247,7 @@ RM_DEV unsigned long long wave_cull_blend(const uint32_t* lunits, uint32_t n_uni
     const uint32_t r = restart_m ? 63u - (uint32_t)__builtin_clzll(restart_m) : 0u;
     const unsigned long long from_r = ~((1ull << r) - 1ull);  // units r .. 63
     // the first unit at or behind the restart that may have raised the accumulator, or behind which nothing is known
-    const unsigned long long poison_m = (opaque_m | (__builtin_amdgcn_ballot_w64((is_sub || is_int) && !skip) & valid)) & from_r;
+    const unsigned long long poison_m = (opaque_m | (__builtin_amdgcn_ballot_w64((is_sub | is_int) & !skip) & valid)) & from_r;
     const unsigned long long behind_poison = poison_m ? ~((2ull << __builtin_ctzll(poison_m)) - 1ull) : 0ull;  // (2 << 63 = 0: none)
     return valid & from_r & (~skip_m | behind_poison | (1ull << r));
 }
@@ -413,8 +416,11 @@ RM_DEV float spec_plane(LdsF r, float qx, float qy, float qz) {
     const lds_f4 n = lds_load4(r);
     return ((qx * n.x + qy * n.y) + qz * n.z) + n.w;  // as exec_command
 }
+// k of a SmoothUnion record as a SCALAR: every lane reads the same LDS word, but the compiler cannot know, and "if (k > 0)" on a vector
+// register is divergent control flow (exec saved, narrowed, restored: a dozen scalar instructions per blend, at 4.3 cycles each)
+RM_DEV float uniform_k(LdsF r) { return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r[0]))); }
 RM_DEV float spec_smooth_union(LdsF r, float a, float b, unsigned long long live) {  // as exec_command, RM_MODE_SMOOTH
-    const float kk = r[0];
+    const float kk = uniform_k(r);
     float v = fmin_(a, b);
     if (kk > 0.0f) {
         const float t = kk - __builtin_fabsf(a - b);
@@ -441,7 +447,7 @@ RM_DEV void guard_fence(SqrtGuard& g) { asm("" : "+v"(g.lo), "+v"(g.hi)); }
 // tap inside the blend zone" test for the four.  A lane outside the zone has h = 0 and gets v - 0 = v: the value the
 // skipping form returns.
 RM_DEV void spec_smooth_union4(LdsF r, const float (&a)[4], const float (&b)[4], unsigned long long live, float (&out)[4]) {
-    const float kk = r[0];
+    const float kk = uniform_k(r);
     float t[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {

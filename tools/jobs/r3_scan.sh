@@ -11,5 +11,6 @@ for round in 1 2; do
   t "generated" g32s 3840 2160 256
   t "generated" g32s 1920 1080 256
   t "generated" g32 1920 1080 256
+  t "interpreter" g32s 1920 1080 256 --specialize 0
 done
 cat "$out/status.txt"
