@@ -469,8 +469,14 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
         void* args[] = {&L, &work, &n_tiles_arg, &refill};
         hipError_t e = hipModuleLaunchKernel(spec_fn, grid.x, grid.y, grid.z, 64u * WPT, 1, 1, (unsigned)shmem, s, args, nullptr);
         if (e != hipSuccess) return fail(c, RM_ERR_DEVICE, "launch of the specialised kernel failed: %s", hipGetErrorString(e));
-    } else if (lds && !ext)
-        hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
+    } else if (lds && !ext) {  // one lean kernel per record loop (c->last_loop: 1 .. 4 here)
+        switch (c->last_loop) {
+        case 1: hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT, 1>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto); break;
+        case 2: hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT, 2>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto); break;
+        case 3: hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT, 3>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto); break;
+        default: hipLaunchKernelGGL((rmk::rm_render_v5_lean<WPT, 4>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto); break;
+        }
+    }
     else if (lds)
         hipLaunchKernelGGL((rmk::rm_render_v5<rmk::ProgLds, true, WPT, true>), grid, dim3(64 * WPT), shmem, s, L, work, n_tiles, refill_auto);
     else if (!ext)

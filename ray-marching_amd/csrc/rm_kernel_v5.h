@@ -737,7 +737,10 @@ struct FalseTag { static constexpr bool value = false; };
 // MAT (extension, materials): compiled into the kernels that can meet a tagged program -- the extension
 // interpreter and the kernels specialised for one; it adds a fifth phase after the four normal taps of a batch of
 // hits (one evaluation of the material program at the hit positions) and a byte per ray next to its result code.
-template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT, bool SPEC, bool MAT = false>
+// LOOP (interpreter kernels): 0 the record loop is chosen at run time from the launch's flags; 1 chain, 2 chain over the records the unit
+// mask names, 3 tree, 4 tree over the records the mask leaves -- a kernel compiled for ONE loop: no dispatch per evaluation, and above
+// all none of the other loops' code and registers (the lean kernel with all four kept 176 scalar registers spilled in vector lanes)
+template <class Prog, bool PROG_IN_LDS, int WPT, bool EXT, bool SPEC, bool MAT = false, int LOOP = 0>
 RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_tiles, uint32_t refill_min) {
     constexpr uint32_t POOL = 1024u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -821,6 +824,10 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 #else
             return ~0ull;
 #endif
+        } else if constexpr (LOOP == 2 || LOOP == 4) {  // (the masked loops are for lattice programs)
+            return wave_cull_lattice(lunits, L.n_grp, x, y, z, thr, is_live, live_mask);
+        } else if constexpr (LOOP == 1 || LOOP == 3) {
+            return ~0ull;
         } else if constexpr (PROG_IN_LDS) {
             if ((L.flags & 8u) == 0u) return ~0ull;
             if (L.unit_mode == RM_UNITS_LATTICE) return wave_cull_lattice(lunits, L.n_grp, x, y, z, thr, is_live, live_mask);
@@ -843,17 +850,17 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 uint32_t again = 0u;
                 v[0] = map_scene_spec<false>(lprog_v, x, y, z, need, live_mask, tiny, again);
             }
-        } else if (L.flags & 4u) {  // chain program (wave-uniform): the stack-free record loop
+        } else if (LOOP == 1 || LOOP == 2 || (LOOP == 0 && (L.flags & 4u))) {  // chain program (wave-uniform): the stack-free record loop
             const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
-            const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;  // (the unit records are staged in LDS with the program)
+            const bool masked = LOOP == 0 ? (PROG_IN_LDS && (L.flags & 8u) != 0u) : LOOP == 2;  // (the unit records are staged in LDS with the program)
 #ifdef RM_INTERP_STATS
             n_eval += (uint32_t)__builtin_popcountll(masked ? need : (L.n_rec >= 64u ? ~0ull : (1ull << L.n_rec) - 1ull));
 #endif
             v[0] = map_scene_chain<true>(prog, L.n_rec, x, y, z, need, masked, tiny);
             if (tiny.any_bad()) v[0] = map_scene_chain<false>(prog, L.n_rec, x, y, z, need, masked, tiny);
-        } else if (!EXT) {  // tree program -- reference node types in any arrangement, all a kernel without the extensions ever gets --:
-                            // one dispatch per record
-            const bool masked = PROG_IN_LDS && (L.flags & 8u) != 0u;
+        } else if (LOOP == 3 || LOOP == 4 || (LOOP == 0 && !EXT)) {  // tree program -- reference node types in any arrangement, all a kernel
+                                                                      // without the extensions ever gets --: one dispatch per record
+            const bool masked = LOOP == 0 ? (PROG_IN_LDS && (L.flags & 8u) != 0u) : LOOP == 4;
             if (masked) {  // ... over the records the wave's unit mask leaves (L.n_tree != 0)
                 const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
                 const TreeKeep k = tree_keep(lunits + 8u * L.n_grp, L.n_rec, need);
@@ -1275,10 +1282,10 @@ __global__ __launch_bounds__(64 * WPT) void rm_render_v5(RmLaunch L, V5Work work
 #ifndef RM_LEAN_WAVES
 #define RM_LEAN_WAVES 6
 #endif
-template <int WPT>
+template <int WPT, int LOOP>
 __global__ __launch_bounds__(64 * WPT) __attribute__((amdgpu_waves_per_eu(RM_LEAN_WAVES, 8)))
 void rm_render_v5_lean(RmLaunch L, V5Work work, uint32_t n_tiles, uint32_t refill_min) {
-    rm_render_v5_body<ProgLds, true, WPT, false, false, false>(L, work, n_tiles, refill_min);
+    rm_render_v5_body<ProgLds, true, WPT, false, false, false, LOOP>(L, work, n_tiles, refill_min);
 }
 
 // ---------------------------------------------------------------------------------------------
