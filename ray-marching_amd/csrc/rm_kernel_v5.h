@@ -931,7 +931,11 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
     float dx = 0.f, dy = 0.f, dz = 0.f, sc = 0.f;
     // itr: the ray's id in the pool (bits 0-9) and the march steps it has taken (bits 10 and up; max_iter <= 65536) in ONE
     // register -- a step adds 1024, the loop bound compares with max_iter << 10 -- the one register between 6 and 5 waves per SIMD
-    uint32_t itr = 0u, mode = M_EMPTY;  // M_EMPTY (idle), M_MARCH, M_RETIRED (nothing left to take)
+    // ... and the lane's state in its top two bits: 0 marching, ITR_EMPTY idle (waiting for a ray), ITR_RETIRED nothing left to take
+    constexpr uint32_t ITR_EMPTY = 0x80000000u, ITR_RETIRED = 0x40000000u;  // (a marching ray's itr stays below 2^27)
+    uint32_t itr = ITR_EMPTY;
+    auto lane_empty = [&]() { return (int32_t)itr < 0; };
+    auto lane_marching = [&]() { return itr < ITR_RETIRED; };
     const uint32_t iter_limit = L.max_iter << 10;
     float thr_base = inf_f;  // SPEC: pruning threshold without its position term ("Pruning")
     // (a hit whose normal is being sampled keeps its state -- position, partial normal -- in LDS: tap phase, below)
@@ -950,14 +954,14 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         if (tap_t == TAP_IDLE) {
             // ---- A. idle lanes take ready rays; when the buffer is empty it is refilled with the
             //         survivors of the next 64 candidates of the pool ----
-            const unsigned long long want0 = __ballot(mode == M_EMPTY);
-            const unsigned long long live0 = __ballot(mode == M_MARCH);
+            const unsigned long long want0 = __ballot(lane_empty());
+            const unsigned long long live0 = __ballot(lane_marching());
             if (want0 != 0ull && (live0 == 0ull || (uint32_t)__popcll(want0) >= refill_min)) {
                 unsigned long long want = want0;
                 while (want != 0ull) {
                     if (rq_pos == rq_cnt) {  // buffer empty: produce
                         if (!pool_open) {
-                            if (mode == M_EMPTY) mode = M_RETIRED;  // pool exhausted and buffer drained
+                            if (lane_empty()) itr = ITR_RETIRED;  // pool exhausted and buffer drained
                             break;
                         }
                         uint32_t base = 0u;
@@ -1000,7 +1004,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                         continue;
                     }
                     const uint32_t avail = rq_cnt - rq_pos, n_want = (uint32_t)__popcll(want);
-                    if (mode == M_EMPTY) {
+                    if (lane_empty()) {
                         const uint32_t rank = lane_rank(want);
                         if (rank < avail) {
                             const uint32_t e = rq_pos + rank;
@@ -1014,17 +1018,16 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                             sc = shared ? 0.0f + f0 : 0.0f;  // dist (wgsl:88), dist += scene_dist (wgsl:114)
                             itr = rid | (shared ? 1024u : 0u);
                             thr_base = shared ? __builtin_fabsf(f0) * 2.00002f : inf_f;
-                            mode = M_MARCH;
                         }
                     }
                     rq_pos += n_want < avail ? n_want : avail;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                    want = __ballot(mode == M_EMPTY);
+                    want = __ballot(lane_empty());
                 }
             }
             // ---- hits waiting for their normal: a tap phase runs when 64 are waiting, or when nothing else is left ----
-            const bool any_live = __ballot(mode == M_MARCH) != 0ull;
-            if (!any_live && __ballot(mode == M_EMPTY) != 0ull) continue;  // idle lanes remain: force a refill round
+            const bool any_live = __ballot(lane_marching()) != 0ull;
+            if (!any_live && __ballot(lane_empty()) != 0ull) continue;  // idle lanes remain: force a refill round
             if (hq_n >= 64u || (!any_live && hq_n != 0u)) {
                 tap_n = hq_n < 64u ? hq_n : 64u;
                 hq_n -= tap_n;  // the most recent tap_n entries: [hq_n, hq_n + tap_n); nothing is pushed during the phase
@@ -1101,7 +1104,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
         // handful of branches less per march step, in a kernel whose scalar side is as busy as its vector side (a CU has one
         // scalar unit for four SIMDs: 4.3 cycles per scalar instruction per SIMD, profiles/r03_ubench_scalar_issue_cycles.txt).
         // The sequence of evaluations is the one the flat loop produced.
-        uint32_t n_idle = tapping ? 0u : (uint32_t)__popcll(__ballot(mode == M_EMPTY));  // wave-uniform: lanes waiting for a ray
+        uint32_t n_idle = tapping ? 0u : (uint32_t)__popcll(__ballot(lane_empty()));  // wave-uniform: lanes waiting for a ray
         for (;;) {
             // (the interpreter kernels keep ONE copy of the evaluation for march steps and taps: their record loops are large, and the
             // loop unswitched on `tapping` costs the lean kernel its registers)
@@ -1128,7 +1131,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
 #endif
             } else {
                 ex = ro.x + dx * sc; ey = ro.y + dy * sc; ez = ro.z + dz * sc;  // wgsl:91
-                is_live = mode == M_MARCH;
+                is_live = lane_marching();
                 thr = thr_base + kPruneAbs * (prune_scale + ((__builtin_fabsf(ex) + __builtin_fabsf(ey)) + __builtin_fabsf(ez)));
             }
             const unsigned long long live_m = __builtin_amdgcn_ballot_w64(is_live);
@@ -1193,7 +1196,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                     hq_rid[e] = itr & 1023u;
 #endif
                     hq_v[e] = ex; hq_v[V5_HQ + e] = ey; hq_v[2u * V5_HQ + e] = ez;
-                    mode = M_EMPTY;
+                    itr = ITR_EMPTY;
                 }
                 hq_n += (uint32_t)__popcll(hit_mask);
             }
@@ -1204,7 +1207,7 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                     const uint32_t e = sq_n + lane_rank(miss_mask);
                     sq_rid[e] = itr & 1023u;
                     sq_v[e] = dx; sq_v[V5_SQ + e] = dy; sq_v[2u * V5_SQ + e] = dz;
-                    mode = M_EMPTY;
+                    itr = ITR_EMPTY;
                 }
                 sq_n += n_miss;
             }
