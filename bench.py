@@ -459,7 +459,8 @@ def run_rank(args):
                 "kernel": "rm_render_v5 (interpreter: LDS-staged records; %s), one frame in flight"
                           % ["general record loop, accumulator machine", "stack-free chain loop",
                              "stack-free chain loop over the records wave-level culling names", "tree loop, one dispatch per record",
-                             "tree loop over the records wave-level culling leaves"][min(loop, 4)],
+                             "tree loop over the records wave-level culling leaves",
+                             "record machine over the units of a blending chain wave-level culling names"][min(loop, 5)],
                 "value": W * H * K / a_el / 1e6, "unit": "Mpixels/s", "kernel_ms": a_k,
                 "same_image": float(full[0][..., :3].double().sum().item()) == checksum or args.camera != "still"}
             res.set_option(_ffi.RM_OPT_SPECIALIZE, args.specialize)

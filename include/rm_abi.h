@@ -174,7 +174,8 @@ enum rm_info {
                                     general one (value stack, every node type; also reported when a specialised kernel ran), 1 the chain loop ("a op b op c ...": no
                                     stack), 2 the chain loop over the records wave-level culling names (exact; the default for chains of a dozen leaves or more staged in
                                     LDS), 3 the tree loop (reference node types in any arrangement: one dispatch per record), 4 the tree loop over the
-                                    records wave-level culling leaves (exact; trees of a dozen leaves or more and at most 128 records, staged in LDS) */
+                                    records wave-level culling leaves (exact; trees of a dozen leaves or more and at most 128 records, staged in LDS), 5 the
+                                    general record machine over the units of a blending chain that wave-level culling names (exact; eight leaves or more) */
     RM_INFO_JIT_FROM_CACHE = 11  /* 1 when the current program's kernel was read from the disk cache of compiled structures
                                   * (RM_JIT_CACHE_DIR; default: jit_cache next to the library) instead of being compiled */
 };

@@ -31,7 +31,7 @@ constexpr uint32_t kMaxIter = 1u << 16;
 constexpr uint32_t kPruneLeaves = 12;  // RM_OPT_PRUNE = 2: programs that EVALUATE this many spheres + boxes (RmDecoded::n_leaves: subtracted
                                         // ones included, they have no miss-test slot but cost the same) get the pruned kernel
 
-constexpr uint32_t kBlendPruneLeaves = 8;  // ... and programs that blend, the local skipping rule (rm_groups.h), from this many
+constexpr uint32_t kBlendPruneLeaves = 8;  // ... and programs that blend, the rules of their chains (rm_units.h), from this many
 thread_local std::string g_create_error;
 
 }  // namespace
@@ -381,12 +381,16 @@ int launch_v5_w(rm_ctx* c, const RmLaunch& L_in, bool lds, uint32_t n_frames, hi
     const bool tree = c->decoded.is_tree && chain_mode > 0;
     static const bool tree_masks = !(std::getenv("RM_TREE_MASKS") && std::atoi(std::getenv("RM_TREE_MASKS")) == 0);  // A/B
     const bool tree_units = tree && !chain && !c->decoded.has_extensions && !c->decoded.tree.empty() && tree_masks && lds;
-    const bool units = c->decoded.unit_mode == RM_UNITS_LATTICE && (chain || tree_units) && chain_mode >= 2 && c->decoded.n_leaves >= kPruneLeaves;
+    // ... and a chain of blends (the wider interpreter: SmoothUnion is an extension): the record machine over the units the mask names
+    static const uint32_t blend_leaves = std::getenv("RM_BLEND_PRUNE_LEAVES") ? (uint32_t)std::atoi(std::getenv("RM_BLEND_PRUNE_LEAVES")) : kBlendPruneLeaves;
+    const bool blend_units = c->decoded.unit_mode == RM_UNITS_BLEND && lds && !chain && chain_mode >= 2 && c->decoded.n_leaves >= blend_leaves;
+    const bool units = blend_units ||
+                       (c->decoded.unit_mode == RM_UNITS_LATTICE && (chain || tree_units) && chain_mode >= 2 && c->decoded.n_leaves >= kPruneLeaves);
     L.n_tree = units && tree_units ? (uint32_t)c->decoded.tree.size() : 0u;
     if (L.n_tree != 0u) L.spill_depth += 1u;  // (map_scene_tree_masked spills at every push)
     L.flags = (cull ? 1u : 0u) | (chain ? 4u : 0u) | (units ? 8u : 0u) | (tree ? 16u : 0u);
     // (the scalar-cache variant has no unit records at hand)
-    c->last_loop = (L.flags & 4u) ? (((L.flags & 8u) && lds) ? 2 : 1) : (tree && !c->decoded.has_extensions) ? (L.n_tree != 0u ? 4 : 3) : 0;
+    c->last_loop = (L.flags & 4u) ? (((L.flags & 8u) && lds) ? 2 : 1) : (tree && !c->decoded.has_extensions) ? (L.n_tree != 0u ? 4 : 3) : blend_units ? 5 : 0;
     // programs that blend: a ray the plain miss tests cannot clear (every bound is inflated by the blend radius) gets the
     // program run on lower bounds of its leaves along the ray.  RM_BOUND_WALK=0 (diagnostics) keeps the plain tests only.
     static const bool bound_walk_on = !(std::getenv("RM_BOUND_WALK") && std::atoi(std::getenv("RM_BOUND_WALK")) == 0);

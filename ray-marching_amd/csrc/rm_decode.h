@@ -66,6 +66,7 @@ struct RmDecoded {
     //         sphere r, box min h, cylinder min(r, hh); with a negative size in it, minus the sum of the absolute sizes
     //   p[5]  the blend radius of the unit's SmoothUnion, max(k, 0); 0 for every other unit
     //   p[6]  the unit's kind (RM_UNIT_*), as an integer
+    //   op    first | last << 16: the records [first, last] behind the unit's bit (not an opcode word)
     // unit_mode: RM_UNITS_LATTICE (prunable programs), RM_UNITS_BLEND (programs that blend whose top level is a chain), or
     // RM_UNITS_NONE -- also when there are more than 64 units.  unit_kmax: the largest p[5].
     std::vector<RmRecord> units;
@@ -326,7 +327,7 @@ static inline int rm_decode_core(uint32_t cmd_count, const uint32_t* words, uint
         for (const RmUnit& u : us) {
             RmRecord g;
             std::memset(&g, 0, sizeof g);
-            g.op = RM_OP(RM_KIND_SPHERE, RM_MODE_PUSH, 0);
+            g.op = (uint32_t)u.first | ((uint32_t)u.last << 16);  // the records the unit's bit guards (the interpreter's walk over a blending chain's units)
             std::memcpy(&g.p[6], &u.kind, 4);
             if (u.leaf < 0) {
                 g.p[3] = inf;

@@ -266,6 +266,31 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     for (int k = 0; k < R; k++) out[k] = acc[k];
 }
 
+// map_scene for a program that BLENDS along a top-level chain (rm_units.h RM_UNITS_BLEND), under the wave's unit mask (rm_kernel_v5.h
+// "Wave-level culling": skip / restart / poison rules).  A unit takes the accumulator to its next value through one or more records
+// -- "leaf fused with its operator", "leaf; SmoothUnion", an opaque stretch --; a unit whose bit is clear leaves the accumulator alone,
+// and the chain starts from +inf (min(+inf, v) = v and smin_k(+inf, v) = v - 0, bit for bit: a restart).  The loop walks the set bits
+// and runs each unit's records [first, last] (row 7 of the unit table) through the general record machine: same functions, same order.
+template <bool FAST, bool EXT, class Prog>
+RM_DEV float map_scene_units(const Prog& prog, const uint32_t* ranges, float* spill, float x, float y, float z, unsigned long long need,
+                             SqrtGuard& tiny, uint32_t xf_base) {
+    float qx[1] = {x}, qy[1] = {y}, qz[1] = {z}, acc[1] = {__uint_as_float(0x7F800000u)};
+    uint32_t sp = 0u;
+    unsigned long long m = need;
+    while (m != 0ull) {
+        const uint32_t u = (uint32_t)__builtin_ctzll(m);
+        m &= m - 1ull;
+        const uint32_t range = __builtin_amdgcn_readfirstlane(ranges[u]);  // (every lane reads the same word)
+        for (uint32_t c = range & 0xFFFFu, last = range >> 16; c <= last; c++) {
+            uint32_t op;
+            float p[7];
+            prog.load(c, op, p);
+            exec_command<1, FAST, EXT, false>(op, p, qx, qy, qz, acc, spill, sp, tiny, xf_base, ~0ull, 0u);
+        }
+    }
+    return acc[0];
+}
+
 // map_scene for a CHAIN program (RmDecoded::is_chain): record 0 pushes a sphere / box, every later record is a sphere / box
 // fused with the Union / Subtraction that consumes it (RM_OP_FASTCLASS != 0) -- what the reference's editor produces for
 // "a op b op c ..." and what both metric scenes are.  No value stack, no opcode ladder: two decisions per record (which

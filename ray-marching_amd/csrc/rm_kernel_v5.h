@@ -173,13 +173,14 @@ RM_DEV WaveBall wave_ball(float x, float y, float z, bool is_live, unsigned long
 }
 // The unit table in LDS, one ROW per field so that lane u's reads do not collide with its neighbours' (unit records are 32
 // bytes apart in device memory; a workgroup transposes them when it stages the program): row f of n_units floats holds
-// RmDecoded::units[u].p[f] -- 0..2 centre, 3 outer radius, 4 inner radius, 5 blend radius, 6 kind.
-constexpr uint32_t kUnitRows = 7u;
+// RmDecoded::units[u].p[f] -- 0..2 centre, 3 outer radius, 4 inner radius, 5 blend radius, 6 kind; row 7 the record's first word (the
+// records the unit stands for, first | last << 16).
+constexpr uint32_t kUnitRows = 8u;
 RM_DEV void stage_units(uint32_t* lunits, const RmRecord* __restrict__ units, uint32_t n_units, uint32_t tid, uint32_t n_threads) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(units);
     for (uint32_t k = tid; k < kUnitRows * n_units; k += n_threads) {
         const uint32_t f = k / n_units, u = k - f * n_units;
-        lunits[k] = src[8u * u + 1u + f];
+        lunits[k] = src[8u * u + ((f + 1u) & 7u)];
     }
 }
 struct UnitBounds { float L, H, k; uint32_t kind; };
@@ -873,11 +874,12 @@ RM_DEV void rm_render_v5_body(const RmLaunch& L, const V5Work& work, uint32_t n_
                 v[0] = map_scene_tree<true>(prog, L.n_rec, spill, x, y, z, tiny);
                 if (tiny.any_bad()) v[0] = map_scene_tree<false>(prog, L.n_rec, spill, x, y, z, tiny);
             }
-        } else if (PROG_IN_LDS && (L.flags & 8u)) {  // the general record loop; records of units the wave does not need are skipped
+        } else if (PROG_IN_LDS && (L.flags & 8u)) {  // a blending chain: the general record machine over the units the wave's mask names
             const unsigned long long need = units_needed(x, y, z, thr, 0.0f, is_live, live_mask);
-            map_scene_multi<1, true, Prog, EXT, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth, need, L.unit_mode);
+            const uint32_t* ranges = lunits + 7u * L.n_grp;  // row 7 of the unit table
+            v[0] = map_scene_units<true, EXT>(prog, ranges, spill, x, y, z, need, tiny, L.value_spill_depth);
             if (tiny.any_bad())  // a sqrt argument outside the fast range (SqrtGuard): redo with the generic sqrt
-                map_scene_multi<1, false, Prog, EXT, true>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth, need, L.unit_mode);
+                v[0] = map_scene_units<false, EXT>(prog, ranges, spill, x, y, z, need, tiny, L.value_spill_depth);
         } else {
             map_scene_multi<1, true, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);
             if (tiny.any_bad()) map_scene_multi<1, false, Prog, EXT>(prog, L.n_rec, spill, L.max_dist, qx, qy, qz, v, tiny, L.value_spill_depth);

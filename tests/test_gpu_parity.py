@@ -158,6 +158,12 @@ def test_interpreter_record_loops(res, oracle, kernel):
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
     assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
     assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == 0
+    # ... unless it is a chain of blends of eight leaves or more with its unit records at hand: the record machine over the units the
+    # wave's mask names (5)
+    cc, w, u = oracle_case(oracle, scenes.EXT_SCENES["g32s"](), W, H, None)
+    setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=kernel)
+    assert_same(res.draw(W, H), oracle.render(u, lim, cc, w, W, H, threads=4))
+    assert res.info(_ffi.RM_INFO_INTERPRETER_LOOP) == (5 if kernel == _ffi.RM_KERNEL_V5_LDS else 0)
     # a specialised kernel reports 0 as well (the loop is the interpreter's)
     cc, w, u = oracle_case(oracle, scenes.g8(), W, H, None)
     setup(res, cc=cc, words=w, u=_ffi.Uniforms.from_buffer_copy(bytes(u)), limits=lim, kernel=KERNEL_SPEC)
