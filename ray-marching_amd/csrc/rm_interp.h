@@ -111,32 +111,18 @@ RM_DEV void xf_rotate_conj(float w, float ax, float ay, float az, float& x, floa
 // One decoded command applied to the R positions of a lane.
 // EXT = false compiles the reference's four node types only (the lean, measured path); EXT = true
 // adds the extension node types.  Which one runs is decided per program on the host.
-// need / unit_mode: the wave's unit mask (rm_kernel_v5.h "Wave-level culling"); a record whose unit's bit is clear is skipped --
-// in a lattice program its leaf is +inf (a pushed leaf still pushes), in a blending chain nothing happens at all (the unit's
-// records leave the stack as they found it; the leaf that starts the chain leaves +inf).
-template <int R, bool FAST, bool EXT = false, bool MASKED = false>
+template <int R, bool FAST, bool EXT = false>
 RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float (&qy)[R], float (&qz)[R], float (&acc)[R],
-                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u, unsigned long long need = ~0ull,
-                         uint32_t unit_mode = 0u) {
+                         float* spill, uint32_t& sp, SqrtGuard& tiny, uint32_t xf_base = 0u) {
     // The opcode is wave-uniform; for the LDS policy it arrives in a VGPR and is made scalar HERE,
     // at its first use, not where the (prefetched) record was loaded: otherwise the wave would
     // wait for the NEXT record's LDS read before starting the current record's arithmetic.
     op = __builtin_amdgcn_readfirstlane(op);
-    const uint32_t un = MASKED ? RM_OP_UNIT(op) : 0u;
-    const bool far = MASKED && un != 0u && ((need >> (un - 1u)) & 1ull) == 0ull;  // wave-uniform
-    if (far && unit_mode == RM_UNITS_BLEND) {
-        if (RM_OP_KIND(op) != RM_KIND_POP && RM_OP_MODE(op) == RM_MODE_PUSH && (op & RM_OP_SPILL) == 0u) {  // the chain's first leaf
-#pragma unroll
-            for (int k = 0; k < R; k++) acc[k] = __uint_as_float(0x7F800000u);
-        }
-        return;
-    }
     // The records of a left-deep chain (RM_OP_FASTCLASS): leaf, then min / max(., -leaf) into the accumulator; no stack slot
     // is read or written, nothing merges with the generic path below (whose value copies at the joins of its kind / spill /
     // mode ladder cost ~6 v_mov, ~8 branches and ~20 scalar instructions per record).
     const uint32_t cls = RM_OP_FASTCLASS(op);
     if (cls != 0u && cls <= 4u) {
-        if (far) return;  // min(acc, +inf), max(acc, -inf)
 #pragma unroll
         for (int k = 0; k < R; k++) {
             const float b = (cls & 1u) ? sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny) : sdf_box_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
@@ -172,10 +158,7 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
             a[k] = spill[(sp * R + k) * 64u];
         }
     } else {
-        if (far) {  // a far leaf of a lattice program
-#pragma unroll
-            for (int k = 0; k < R; k++) b[k] = __uint_as_float(0x7F800000u);
-        } else if (kind == RM_KIND_SPHERE) {
+        if (kind == RM_KIND_SPHERE) {
 #pragma unroll
             for (int k = 0; k < R; k++) b[k] = sdf_sphere_t<FAST>(qx[k], qy[k], qz[k], p, tiny);
         } else if (!EXT || kind == RM_KIND_BOX) {
@@ -226,10 +209,10 @@ RM_DEV void exec_command(uint32_t op, const float (&p)[7], float (&qx)[R], float
 // map_scene (wgsl:187-203) for R positions per lane.  Commands are fetched one ahead of their
 // use (two buffers, loop unrolled by two) so that the fetch latency hides behind the VALU work
 // of the previous command.
-template <int R, bool FAST, class Prog, bool EXT = false, bool MASKED = false>
+template <int R, bool FAST, class Prog, bool EXT = false>
 RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, float max_dist, const float (&qx_in)[R],
                             const float (&qy_in)[R], const float (&qz_in)[R], float (&out)[R], SqrtGuard& tiny,
-                            uint32_t xf_base = 0u, unsigned long long need = ~0ull, uint32_t unit_mode = 0u) {
+                            uint32_t xf_base = 0u) {
     float qx[R], qy[R], qz[R];  // transform commands (EXT) change the evaluation position
 #pragma unroll
     for (int k = 0; k < R; k++) { qx[k] = qx_in[k]; qy[k] = qy_in[k]; qz[k] = qz_in[k]; }
@@ -247,7 +230,7 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
         uint32_t op0;
         float p0[7];
         prog.load(c, op0, p0);
-        exec_command<R, FAST, EXT, MASKED>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
     }
 #else
     uint32_t op0, op1;
@@ -255,10 +238,10 @@ RM_DEV void map_scene_multi(const Prog& prog, uint32_t n_rec, float* spill, floa
     prog.load(0u, op0, p0);
     for (;;) {
         prog.load(c + 1u < n_rec ? c + 1u : c, op1, p1);
-        exec_command<R, FAST, EXT, MASKED>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
+        exec_command<R, FAST, EXT>(op0, p0, qx, qy, qz, acc, spill, sp, tiny, xf_base);
         if (++c == n_rec) break;
         prog.load(c + 1u < n_rec ? c + 1u : c, op0, p0);
-        exec_command<R, FAST, EXT, MASKED>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base, need, unit_mode);
+        exec_command<R, FAST, EXT>(op1, p1, qx, qy, qz, acc, spill, sp, tiny, xf_base);
         if (++c == n_rec) break;
     }
 #endif
@@ -285,7 +268,7 @@ RM_DEV float map_scene_units(const Prog& prog, const uint32_t* ranges, float* sp
             uint32_t op;
             float p[7];
             prog.load(c, op, p);
-            exec_command<1, FAST, EXT, false>(op, p, qx, qy, qz, acc, spill, sp, tiny, xf_base, ~0ull, 0u);
+            exec_command<1, FAST, EXT>(op, p, qx, qy, qz, acc, spill, sp, tiny, xf_base);
         }
     }
     return acc[0];
