@@ -320,8 +320,15 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
             if (m == RM_MODE_PUSH || (m == RM_MODE_INTER && q.kind == RM_UNIT_LEAF)) return false;  // (skipped, these are +inf)
             return true;
         };
+        // ... or starts a value of its own: a pushed leaf (skipped: +inf), which the units that flow behind it take on -- "leaf; leaf op"
+        // pairs are what a balanced tree is made of, and the leaf that starts a chain joins the chain's first group
+        auto pushes = [&](size_t u) {
+            const RmUnit& q = units[u];
+            if (q.kind == RM_UNIT_OPAQUE || q.leaf < 0 || q.k_rec >= 0 || q.first != q.last) return false;
+            return RM_OP_MODE(rec[(size_t)q.first].op) == RM_MODE_PUSH;
+        };
         for (size_t u = 0; u < units.size();) {
-            if (!flows(u)) { u++; continue; }
+            if (!flows(u) && !(pushes(u) && u + 1 < units.size() && flows(u + 1) && units[u + 1].first == units[u].last + 1)) { u++; continue; }
             size_t e = u;  // the run [u, e] of consecutive units, consecutive in the records as well
             while (e + 1 < units.size() && flows(e + 1) && units[e + 1].first == units[e].last + 1) e++;
             for (size_t g = u; g <= e;) {
@@ -346,11 +353,16 @@ inline bool generate_scene_code(const std::vector<RmRecord>& rec, int prune, int
         const RmUnit& u = units[(size_t)ui];
         const uint32_t kind = RM_OP_KIND(rec[i].op), mode = RM_OP_MODE(rec[i].op);
         const int c = pos.back();
-        if (group_left == 0 && group_first[(size_t)ui] != 0) {  // a group starts: its value is the accumulator unless something inside is needed
-            if (stack.empty()) return false;
+        if (group_left == 0 && group_first[(size_t)ui] != 0) {  // a group starts: its value is the accumulator -- or +inf, if the group starts with
+                                                                // a pushed leaf -- unless something inside is needed
+            const bool fresh = mode == RM_MODE_PUSH && u.k_rec < 0;
+            if (!fresh && stack.empty()) return false;
             group_left = group_first[(size_t)ui];
             group_value = nv++;
-            for (int t = 0; t < T; t++) { std::snprintf(line, sizeof line, "    float %s = %s;\n", V(group_value, t).c_str(), V(stack.back(), t).c_str()); s += line; }
+            for (int t = 0; t < T; t++) {
+                std::snprintf(line, sizeof line, "    float %s = %s;\n", V(group_value, t).c_str(), fresh ? "inf" : V(stack.back(), t).c_str());
+                s += line;
+            }
             uint32_t mask = 0u;
             for (int k = 0; k < group_left; k++) mask |= 1u << ((ui + k) & 31);
             std::snprintf(line, sizeof line, "    { const uint32_t wg = unit_word(need, %du);\n    if ((wg & 0x%xu) != 0u) {\n", ui, mask);

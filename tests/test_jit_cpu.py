@@ -38,21 +38,21 @@ def test_generated_code_follows_the_postfix_program(oracle):
     body = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True))]
     assert body == [
         # every bounded leaf is a UNIT behind one bit of `need`, the mask wave-level culling computed for the whole wave
-        # (rm_kernel_v5.h); skipped, a pushed leaf is +inf and a fused one leaves the accumulator alone
+        # (rm_kernel_v5.h); skipped, a pushed leaf is +inf and a fused one leaves the accumulator alone.  Up to four consecutive
+        # units -- a pushed leaf and the units that take its value on -- sit behind one more test on a word of the mask -- is ANY
+        # of them needed --, which the tests inside share: most groups are skipped whole (rm_jit.h "GROUPS of units")
         "const float inf = __uint_as_float(0x7F800000u);",
         "const float x0 = qx, y0 = qy, z0 = qz;",
         "float v0 = inf;",
-        "if (unit_needed(need, 0u)) {",
-        "v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);",      # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
+        "{ const uint32_t wg = unit_word(need, 0u);",
+        "if ((wg & 0xfu) != 0u) {",
+        "float v1 = inf;",
+        "if (unit_in_word(wg, 0u)) {",
+        "v1 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);",      # (records are staged rotated by one dword: parameters at dwords 0..6 of their 8)
         "}",
-        # up to four consecutive units that take the accumulator to its next value sit behind one more test on a word of the mask
-        # -- is ANY of them needed --, which the tests inside share: most groups are skipped whole (rm_jit.h "GROUPS of units")
-        "float v1 = v0;",
-        "{ const uint32_t wg = unit_word(need, 1u);",
-        "if ((wg & 0xeu) != 0u) {",
-        "float v2 = v0;",
+        "float v2 = v1;",
         "if (unit_in_word(wg, 1u)) {",
-        "v2 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
+        "v2 = vmin(v1, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));",
         "}",
         "float v3 = v2;",
         "if (unit_in_word(wg, 2u)) {",
@@ -65,12 +65,13 @@ def test_generated_code_follows_the_postfix_program(oracle):
         "v4 = vmin(v3, spec_box<FAST>(lp + 24, x0, y0, z0, tiny));",
         "}",
         "__builtin_amdgcn_sched_barrier(0);",
-        "v1 = v4;",
+        "v0 = v4;",
         "} }",
-        "return v1;",
+        "return v0;",
     ]
     ungrouped = [l.strip() for l in map_scene_body(renderer.jit_source(cc, w, prune=True, env={"RM_JIT_UNIT_GROUPS": "0"}))]
-    assert ungrouped[6:10] == ["float v1 = v0;", "if (unit_needed(need, 1u)) {", "v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));", "}"]
+    assert ungrouped[2:10] == ["float v0 = inf;", "if (unit_needed(need, 0u)) {", "v0 = spec_sphere<FAST>(lp + 0, x0, y0, z0, tiny);", "}",
+                               "float v1 = v0;", "if (unit_needed(need, 1u)) {", "v1 = vmin(v0, spec_box<FAST>(lp + 8, x0, y0, z0, tiny));", "}"]
     assert ungrouped[-2:] == ["__builtin_amdgcn_sched_barrier(0);", "return v3;"]
 
 
@@ -332,12 +333,14 @@ def test_four_taps_in_one_pass_function(oracle):
     assert body[-4:] == ["f[%d] = v3_%d;" % (t, t) for t in range(4)]
     pruned = taps_body(renderer.jit_source(cc, w, prune=True))
     k = pruned.index("float v0_0 = inf;")
-    assert pruned[k:k + 11] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",
-                                "if (unit_needed(need, 0u)) {",       # one bit of the wave's unit mask for the four taps of a leaf
-                                "v0_0 = spec_sphere<FAST>(lp + 0, x0_0, y0_0, z0_0, tiny);",
-                                "v0_1 = spec_sphere<FAST>(lp + 0, x0_1, y0_1, z0_1, tiny);",
-                                "v0_2 = spec_sphere<FAST>(lp + 0, x0_2, y0_2, z0_2, tiny);",
-                                "v0_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}", "guard_fence(tiny);"]
+    assert pruned[k:k + 17] == ["float v0_0 = inf;", "float v0_1 = inf;", "float v0_2 = inf;", "float v0_3 = inf;",      # the value of the group of four units
+                                "{ const uint32_t wg = unit_word(need, 0u);", "if ((wg & 0xfu) != 0u) {",
+                                "float v1_0 = inf;", "float v1_1 = inf;", "float v1_2 = inf;", "float v1_3 = inf;",
+                                "if (unit_in_word(wg, 0u)) {",       # one bit of the wave's unit mask for the four taps of a leaf
+                                "v1_0 = spec_sphere<FAST>(lp + 0, x0_0, y0_0, z0_0, tiny);",
+                                "v1_1 = spec_sphere<FAST>(lp + 0, x0_1, y0_1, z0_1, tiny);",
+                                "v1_2 = spec_sphere<FAST>(lp + 0, x0_2, y0_2, z0_2, tiny);",
+                                "v1_3 = spec_sphere<FAST>(lp + 0, x0_3, y0_3, z0_3, tiny);", "}", "guard_fence(tiny);"]
     # transforms: every scope gets four positions; smooth unions: the four blends behind ONE blend-zone test
     cc, w = serialize(oracle, scenes.xform_mix())
     src = renderer.jit_source(cc, w)
